@@ -1,0 +1,35 @@
+"""CPU oracle for the Pix2Pix_Turbo / CycleGAN_Turbo forward path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker.  The product path
+(``img2img-turbo_amd/``) never imports this package and fails loudly when the
+HIP library is missing.
+
+What it is: a pure-PyTorch, CPU, fp32 restatement of the reference forward
+
+    src/pix2pix_turbo.py:186-219   (Pix2Pix_Turbo.forward)
+    src/cyclegan_turbo.py:199-207  (CycleGAN_Turbo.forward_with_networks)
+    src/model.py:7-54              (1-step scheduler, patched VAE forwards)
+
+The arithmetic of that path lives in un-vendored third-party packages that are
+NOT present under /root/reference nor installed in this image:
+``diffusers==0.25.1`` (environment.yaml:33), ``peft`` (unpinned,
+environment.yaml:31), ``transformers==4.35.2`` (environment.yaml:25).  Their
+published algorithms (AutoencoderKL, UNet2DConditionModel, DDPMScheduler.step,
+peft LoRA Linear/Conv2d) are restated here with the exact state-dict key names
+those packages use, so real SD-Turbo weights + the reference's ``.pkl``
+checkpoints drop in unchanged.
+
+PARITY UNPINNED: the reference ships no tests, no golden vectors and no
+fixtures for this path, and the reference itself cannot be
+executed here (diffusers/peft missing, no network, no weights).  The oracle is
+therefore pinned only by (a) analytic known-answer tests (scheduler constants,
+time-embedding values, LoRA merged == unmerged, TwinConv folded == unfolded,
+zero skip-conv => skips inert, gamma=1 stochastic == deterministic), (b)
+exact parameter-count checks against the published SD-2.1/SD-Turbo sizes
+(865,910,724 UNet / 83,653,863 VAE parameters) and (c) for the CLIP text tower,
+the installed ``transformers`` implementation.  See tests/test_oracle_kats.py.
+"""
+
+from .arch import VAEArch, UNetArch, SD_TURBO_VAE, SD_TURBO_UNET, TINY_VAE, TINY_UNET  # noqa: F401

@@ -1,0 +1,158 @@
+"""Functional building blocks over a flat state dict (test infrastructure).
+
+Restates diffusers 0.25.1 ``models/resnet.py``, ``attention_processor.py``,
+``attention.py``, ``transformer_2d.py`` and peft ``tuners/lora/layer.py``
+semantics.  Every layer is addressed by its
+diffusers/peft state-dict key so real checkpoints drop in.
+"""
+import math
+import re
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+_LORA_A = re.compile(r"\.lora_A\.([^.]+)\.weight$")
+
+
+class Weights:
+    """A state dict + per-adapter LoRA scaling (= lora_alpha / r * adapter weight).
+
+    peft keeps ``scaling`` on the module, not in the state dict, so it travels
+    beside the tensors here.
+    """
+
+    def __init__(self, sd: Dict[str, torch.Tensor], scaling: Optional[Dict[str, float]] = None):
+        self.sd = sd
+        self.scaling = dict(scaling or {})
+        self._adapters = {}
+        for k in sd:
+            m = _LORA_A.search(k)
+            if m:
+                self._adapters.setdefault(k[: m.start()], []).append(m.group(1))
+
+    def has(self, key):
+        return key in self.sd
+
+    def get(self, key):
+        return self.sd[key]
+
+    def adapters_of(self, name):
+        return self._adapters.get(name, [])
+
+    def base(self, name):
+        """(weight, bias-or-None) of layer ``name`` whether or not peft wrapped it."""
+        if name + ".base_layer.weight" in self.sd:
+            return self.sd[name + ".base_layer.weight"], self.sd.get(name + ".base_layer.bias")
+        return self.sd[name + ".weight"], self.sd.get(name + ".bias")
+
+    def merged(self, name):
+        """(W', b) with W' = W + sum_adapters scaling * B.A  (peft merge; A.7)."""
+        w, b = self.base(name)
+        for ad in self.adapters_of(name):
+            A = self.sd[f"{name}.lora_A.{ad}.weight"]
+            B = self.sd[f"{name}.lora_B.{ad}.weight"]
+            s = self.scaling.get(ad, 1.0)
+            if w.dim() == 4:
+                dw = torch.einsum("ok,kihw->oihw", B[:, :, 0, 0].double(), A.double())
+            else:
+                dw = B.double() @ A.double()
+            w = (w.double() + s * dw).to(w.dtype)
+        return w, b
+
+
+def conv2d(W: Weights, name, x, stride=1, padding=0):
+    """base conv + unmerged LoRA side branch: y = W x + s * B(A x)."""
+    w, b = W.base(name)
+    y = F.conv2d(x, w, b, stride=stride, padding=padding)
+    for ad in W.adapters_of(name):
+        A = W.get(f"{name}.lora_A.{ad}.weight")
+        B = W.get(f"{name}.lora_B.{ad}.weight")
+        y = y + W.scaling.get(ad, 1.0) * F.conv2d(F.conv2d(x, A, None, stride=stride, padding=padding), B)
+    return y
+
+
+def linear(W: Weights, name, x):
+    w, b = W.base(name)
+    y = F.linear(x, w, b)
+    for ad in W.adapters_of(name):
+        A = W.get(f"{name}.lora_A.{ad}.weight")
+        B = W.get(f"{name}.lora_B.{ad}.weight")
+        y = y + W.scaling.get(ad, 1.0) * F.linear(F.linear(x, A), B)
+    return y
+
+
+def group_norm(W: Weights, name, x, groups, eps):
+    return F.group_norm(x, groups, W.get(name + ".weight"), W.get(name + ".bias"), eps)
+
+
+def layer_norm(W: Weights, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), W.get(name + ".weight"), W.get(name + ".bias"), eps)
+
+
+def resnet_block(W: Weights, p, x, groups, eps, temb=None):
+    """ResnetBlock2D (A.2): conv_shortcut iff key present; output_scale_factor 1."""
+    h = F.silu(group_norm(W, p + ".norm1", x, groups, eps))
+    h = conv2d(W, p + ".conv1", h, padding=1)
+    if temb is not None:
+        w, b = W.base(p + ".time_emb_proj")  # never LoRA-adapted in the reference
+        h = h + F.linear(F.silu(temb), w, b)[:, :, None, None]
+    h = F.silu(group_norm(W, p + ".norm2", h, groups, eps))
+    h = conv2d(W, p + ".conv2", h, padding=1)
+    if W.has(p + ".conv_shortcut.weight") or W.has(p + ".conv_shortcut.base_layer.weight"):
+        x = conv2d(W, p + ".conv_shortcut", x)
+    return x + h
+
+
+def attention(W: Weights, p, x, ctx, heads):
+    """Attention + AttnProcessor2_0 on token tensors [B,T,C] (no mask, not causal)."""
+    q = linear(W, p + ".to_q", x)
+    k = linear(W, p + ".to_k", ctx)
+    v = linear(W, p + ".to_v", ctx)
+    B, T, C = q.shape
+    d = C // heads
+    q = q.view(B, T, heads, d).transpose(1, 2)
+    k = k.view(B, -1, heads, d).transpose(1, 2)
+    v = v.view(B, -1, heads, d).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(d))
+    o = torch.softmax(s, dim=-1) @ v
+    o = o.transpose(1, 2).reshape(B, T, C)
+    return linear(W, p + ".to_out.0", o)
+
+
+def vae_attention(W: Weights, p, x, groups, eps):
+    """VAE mid attention: 1 head of width C, GroupNorm inside, residual (A.2)."""
+    B, C, H, Wd = x.shape
+    h = group_norm(W, p + ".group_norm", x.view(B, C, H * Wd), groups, eps)
+    h = h.transpose(1, 2)  # [B, HW, C]
+    o = attention(W, p, h, h, heads=1)
+    return x + o.transpose(1, 2).reshape(B, C, H, Wd)
+
+
+def basic_transformer_block(W: Weights, p, x, ctx, heads):
+    x = x + attention(W, p + ".attn1", layer_norm(W, p + ".norm1", x), layer_norm(W, p + ".norm1", x), heads)
+    x = x + attention(W, p + ".attn2", layer_norm(W, p + ".norm2", x), ctx, heads)
+    h = layer_norm(W, p + ".norm3", x)
+    h = linear(W, p + ".ff.net.0.proj", h)
+    a, g = h.chunk(2, dim=-1)
+    h = a * F.gelu(g)  # exact erf gelu
+    return x + linear(W, p + ".ff.net.2", h)
+
+
+def transformer_2d(W: Weights, p, x, ctx, heads, groups):
+    """Transformer2DModel, use_linear_projection=True, 1 layer; entry GN eps 1e-6."""
+    B, C, H, Wd = x.shape
+    h = group_norm(W, p + ".norm", x, groups, 1e-6)
+    h = h.permute(0, 2, 3, 1).reshape(B, H * Wd, C)
+    h = linear(W, p + ".proj_in", h)
+    h = basic_transformer_block(W, p + ".transformer_blocks.0", h, ctx, heads)
+    h = linear(W, p + ".proj_out", h)
+    return x + h.reshape(B, H, Wd, C).permute(0, 3, 1, 2)
+
+
+def timestep_embedding(t: int, dim: int) -> torch.Tensor:
+    """get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0) -> [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = float(t) * freqs
+    return torch.cat([torch.cos(arg), torch.sin(arg)])[None]
