@@ -1,0 +1,86 @@
+"""Micro-benchmark of the implicit-GEMM kernel on the conv / linear shapes of the 512x512 forward.
+
+    python benchmarks/bench_ops.py [--dtype bf16] [--batch 8] [--out gpurun_out/bench_ops.json]
+
+Uses HIP events around single launches (i2i_run_timed), random (not zero) operands.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from img2img_turbo_amd import _capi as K, ops as O  # noqa: E402
+
+SHAPES = [  # (name, cin, cout, H, W, ks, stride, ups, gn)
+    ("vae 128->128@512 gn", 128, 128, 512, 512, 3, 1, 0, 1),
+    ("vae 128->128@512", 128, 128, 512, 512, 3, 1, 0, 0),
+    ("vae 256->256@256 gn", 256, 256, 256, 256, 3, 1, 0, 1),
+    ("vae 512->512@128 gn", 512, 512, 128, 128, 3, 1, 0, 1),
+    ("vae 512->512@64 gn", 512, 512, 64, 64, 3, 1, 0, 1),
+    ("vae up 256->256 @256->512", 256, 256, 256, 256, 3, 1, 1, 0),
+    ("vae up 512->512 @128->256", 512, 512, 128, 128, 3, 1, 1, 0),
+    ("vae 256->128@512 gn", 256, 128, 512, 512, 3, 1, 0, 1),
+    ("vae conv_in 3->128@512", 8, 128, 512, 512, 3, 1, 0, 0),
+    ("vae conv_out 128->3@512 gn", 128, 3, 512, 512, 3, 1, 0, 1),
+    ("vae down 128@512 s2", 128, 128, 512, 512, 3, 2, 0, 0),
+    ("unet 320->320@64 gn", 320, 320, 64, 64, 3, 1, 0, 1),
+    ("unet 640->640@32 gn", 640, 640, 32, 32, 3, 1, 0, 1),
+    ("unet 1280->1280@16 gn", 1280, 1280, 16, 16, 3, 1, 0, 1),
+    ("unet 1280->1280@8 gn", 1280, 1280, 8, 8, 3, 1, 0, 1),
+    ("unet 2560->1280@8 gn", 2560, 1280, 8, 8, 3, 1, 0, 1),
+    ("unet lin 320->2560 T4096", 320, 2560, 64, 64, 1, 1, 0, 0),
+    ("unet lin 1280->1280 T256", 1280, 1280, 16, 16, 1, 1, 0, 0),
+    ("vae skip 128->256@512 1x1", 128, 256, 512, 512, 1, 1, 0, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--tiles", default="0")
+    ap.add_argument("--out", default="gpurun_out/bench_ops.json")
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    peak = 157.3 if a.dtype == "f32" else 2500.0
+    lib = K.default_library()
+    dev = "cuda"
+    res = []
+    for name, cin, cout, H, W, ks, stride, ups, gn in SHAPES:
+        B = a.batch
+        x = torch.randn(B, H, W, cin, device=dev).to(dt)
+        w = (torch.randn(cout, ks * ks * cin, device=dev) / math.sqrt(ks * ks * cin)).to(dt)
+        ho, wo = (H << ups) // stride, (W << ups) // stride
+        coutp = (cout + 7) // 8 * 8
+        out = torch.empty(B, ho, wo, coutp, device=dev, dtype=dt)
+        bias = torch.randn(cout, device=dev)
+        ss = torch.randn(B, cin, 2, device=dev) if gn else None
+        for tile in [int(t) for t in a.tiles.split(",")]:
+            prog = K.Program()
+            for _ in range(a.iters + 1):
+                prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
+                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile), dt))
+            prog.freeze()
+            ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]
+            t = sorted(ms)[len(ms) // 2]
+            fl = 2.0 * B * ho * wo * cout * ks * ks * cin
+            tf = fl / (t * 1e-3) / 1e12
+            rec = dict(name=name, tile=tile, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
+            res.append(rec)
+            print("%-32s tile %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (name, tile, t, tf, 100 * tf / peak), flush=True)
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def _op(op, dt):
+    return op[0], O.DT[dt], op[1]
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""Build libi2i_turbo.so (gfx950) in-tree with hipcc.  No GPU needed: hipcc cross-compiles.
+
+    python img2img-turbo_amd/csrc/build.py [--force] [-j N]
+
+One object per .hip source (parallel), then one shared library next to this file.  The .so is
+git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["igemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
+LIB = os.path.join(HERE, "libi2i_turbo.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+    if force or _stale(obj, deps):
+        cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, jobs=None):
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    print(build(a.force, a.j))

@@ -1,0 +1,163 @@
+// Boundary and latent-space elementwise kernels for gfx950 (all HBM-bound, one thread per pixel):
+//   NCHW <-> NHWC conversion at the .forward() boundary (torch callers hand NCHW; the kernels run NHWC),
+//   DiagonalGaussianDistribution.sample()*scaling_factor + the stochastic mix (src/pix2pix_turbo.py:198,210),
+//   DDPMScheduler.step + /scaling_factor + post_quant_conv (src/pix2pix_turbo.py:200-203).
+#include "i2i_dev.h"
+#include "launch.h"
+
+namespace {
+
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const i2i_nchw_to_nhwc_params p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t img = i / hw, px = i - img * hw;
+        const S* x = (const S*)p.x + img * p.c * hw + px;
+        T* y = (T*)p.y + i * p.cpad;
+        for (int c = 0; c < p.cpad; ++c) y[c] = (c < p.c) ? from_f32<T>((float)x[(int64_t)c * hw] * p.mul + p.add) : from_f32<T>(0.f);
+    }
+}
+
+template <typename T, typename D>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const i2i_nhwc_to_nchw_params p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t img = i / hw, px = i - img * hw;
+        const T* x = (const T*)p.x + i * p.ldx;
+        D* y = (D*)p.y + img * p.c * hw + px;
+        for (int c = 0; c < p.c; ++c) {
+            float v = to_f32<T>(x[c]);
+            if (p.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+            y[(int64_t)c * hw] = (D)v;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void posterior_kernel(const i2i_posterior_params p) {
+    const int64_t total = (int64_t)p.n * p.hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t img = i / p.hw, px = i - img * p.hw;
+        const T* m = (const T*)p.moments + i * p.ldm;
+        const float* mf = (const float*)p.moments + i * p.ldm;
+        T* u = (T*)p.u + i * p.ldu;
+        for (int c = 0; c < p.ldu; ++c) {
+            float v = 0.f;
+            if (c < p.lat) {
+                const float mean = p.moments_f32 ? mf[c] : to_f32<T>(m[c]);
+                const float logvar = fminf(fmaxf(p.moments_f32 ? mf[p.lat + c] : to_f32<T>(m[p.lat + c]), -30.f), 20.f);
+                const float e = p.eps[(img * p.lat + c) * p.hw + px];
+                v = (mean + __expf(0.5f * logvar) * e) * p.sf;
+                if (p.noise) {
+                    const int64_t nimg = (p.noise_n == 1) ? 0 : img;
+                    v = v * p.r + p.noise[(nimg * p.lat + c) * p.hw + px] * (1.f - p.r);
+                }
+            }
+            u[c] = from_f32<T>(v);
+            if (p.u_f32 && c < p.lat) p.u_f32[i * p.lat + c] = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ddpm_kernel(const i2i_ddpm_params p) {
+    const int64_t total = (int64_t)p.n * p.hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const T* u = (const T*)p.u + i * p.ldu;
+        const T* e = (const T*)p.e + i * p.lde;
+        T* y = (T*)p.y + i * p.ldy;
+        float x0[8];
+        const float* uf = (const float*)p.u + i * p.ldu;
+        const float* ef = (const float*)p.e + i * p.lde;
+        for (int c = 0; c < p.lat; ++c) {
+            const float uv = p.u_f32 ? uf[c] : to_f32<T>(u[c]);
+            const float ev = p.e_f32 ? ef[c] : to_f32<T>(e[c]);
+            x0[c] = ((uv - p.sqrt_1m_abar * ev) / p.sqrt_abar) / p.sf;
+        }
+        for (int o = 0; o < p.ldy; ++o) {
+            float v = 0.f;
+            if (o < p.lat) {
+                v = p.bpq[o];
+                for (int c = 0; c < p.lat; ++c) v += p.wpq[o * p.lat + c] * x0[c];
+            }
+            y[o] = from_f32<T>(v);
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n) {
+    const int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int i2i_nchw_to_nhwc(const i2i_nchw_to_nhwc_params* p, int dtype, void* stream) {
+    if (!p || !p->x || !p->y || p->cpad < p->c) return i2i::fail(I2I_ERR_BAD_ARG, "nchw_to_nhwc: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for((int64_t)p->n * p->h * p->w);
+    const bool src_f32 = p->src_dtype == I2I_F32;
+    if (!src_f32 && p->src_dtype != dtype) return i2i::fail(I2I_ERR_BAD_ARG, "nchw_to_nhwc: src dtype must be f32 or the compute dtype");
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_BF16:
+            if (src_f32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16, float>), dim3(g), dim3(256), 0, s, *p);
+            else hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16, __bf16>), dim3(g), dim3(256), 0, s, *p);
+            break;
+        case I2I_F16:
+            if (src_f32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16, float>), dim3(g), dim3(256), 0, s, *p);
+            else hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16, _Float16>), dim3(g), dim3(256), 0, s, *p);
+            break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "nchw_to_nhwc: bad dtype");
+    }
+    return i2i::check_launch("nchw_to_nhwc");
+}
+
+extern "C" int i2i_nhwc_to_nchw(const i2i_nhwc_to_nchw_params* p, int dtype, void* stream) {
+    if (!p || !p->x || !p->y || p->ldx < p->c) return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_nchw: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for((int64_t)p->n * p->h * p->w);
+    const bool dst_f32 = p->dst_dtype == I2I_F32;
+    if (!dst_f32 && p->dst_dtype != dtype) return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_nchw: dst dtype must be f32 or the compute dtype");
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, float>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_BF16:
+            if (dst_f32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<__bf16, float>), dim3(g), dim3(256), 0, s, *p);
+            else hipLaunchKernelGGL((nhwc_to_nchw_kernel<__bf16, __bf16>), dim3(g), dim3(256), 0, s, *p);
+            break;
+        case I2I_F16:
+            if (dst_f32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<_Float16, float>), dim3(g), dim3(256), 0, s, *p);
+            else hipLaunchKernelGGL((nhwc_to_nchw_kernel<_Float16, _Float16>), dim3(g), dim3(256), 0, s, *p);
+            break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_nchw: bad dtype");
+    }
+    return i2i::check_launch("nhwc_to_nchw");
+}
+
+extern "C" int i2i_posterior(const i2i_posterior_params* p, int dtype, void* stream) {
+    if (!p || !p->moments || !p->eps || !p->u) return i2i::fail(I2I_ERR_BAD_ARG, "posterior: null pointer");
+    if (p->ldm < 2 * p->lat || p->ldu < p->lat) return i2i::fail(I2I_ERR_BAD_ARG, "posterior: bad leading dims");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for((int64_t)p->n * p->hw);
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((posterior_kernel<float>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((posterior_kernel<__bf16>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((posterior_kernel<_Float16>), dim3(g), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "posterior: bad dtype");
+    }
+    return i2i::check_launch("posterior");
+}
+
+extern "C" int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream) {
+    if (!p || !p->u || !p->e || !p->y || !p->wpq || !p->bpq) return i2i::fail(I2I_ERR_BAD_ARG, "ddpm: null pointer");
+    if (p->lat > 8 || p->ldy < p->lat) return i2i::fail(I2I_ERR_BAD_ARG, "ddpm: latent channels must be <= 8");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for((int64_t)p->n * p->hw);
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((ddpm_kernel<float>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((ddpm_kernel<__bf16>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((ddpm_kernel<_Float16>), dim3(g), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "ddpm: bad dtype");
+    }
+    return i2i::check_launch("ddpm");
+}

@@ -1,0 +1,81 @@
+// Device-side vocabulary shared by the gfx950 kernels: element types, 16-byte chunks, MFMA wrappers.
+//
+// Every contraction operand moves as 16-byte "chunks" (8 x bf16/f16 or 4 x f32): one global_load_dwordx4
+// per lane, one ds_write_b128 / ds_read_b128 per chunk, and one chunk per lane feeds
+//   - 16-bit: ONE v_mfma_f32_16x16x32_{bf16,f16}   (lane l holds k = 8*(l>>4) .. +8)
+//   - f32   : FOUR v_mfma_f32_16x16x4_f32, MFMA j consuming element j of the chunk.  Any k->lane
+//             assignment is valid as long as A and B use the same one, so the f32 path keeps the
+//             wide LDS reads of the 16-bit path (exact f32 = fmaf chain; the 1e-3 parity mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/i2i_turbo.h"
+
+extern "C" __shared__ __attribute__((aligned(16))) char i2i_smem[];   // the only LDS object (G17)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int EPC = 4;            // elements per 16-byte chunk
+    static constexpr int DT = I2I_F32;
+    typedef f32x4 chunk_t;
+};
+template <> struct Elem<__bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = I2I_BF16;
+    typedef bf16x8 chunk_t;
+};
+template <> struct Elem<_Float16> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = I2I_F16;
+    typedef f16x8 chunk_t;
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::chunk_t zero_chunk() {
+    typename Elem<T>::chunk_t z;
+#pragma unroll
+    for (int j = 0; j < Elem<T>::EPC; ++j) z[j] = (T)0.0f;
+    return z;
+}
+
+// acc(16x16 f32 fragment) += A-chunk x B-chunk
+__device__ __forceinline__ f32x4 mma_chunk(f32x4 a, f32x4 b, f32x4 acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x4 mma_chunk(bf16x8 a, bf16x8 b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma_chunk(f16x8 a, f16x8 b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// LDS tile geometry common to A and B tiles: rows of 128 bytes = 8 chunks; chunk kc of row r is stored
+// at physical chunk kc ^ ((r >> 1) & 7).  With this XOR a ds_read_b128 wave access (lane -> row l&15,
+// chunk 4*kg + (l>>4)) touches 16 distinct 16-byte slots in each of its four 16-lane service groups
+// (cdna_hip_programming.md section 2 / T2), and the 8-lane ds_write_b128 groups stay conflict-free.
+__device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}

@@ -1,0 +1,289 @@
+// Normalisation and softmax kernels for gfx950: GroupNorm statistics (two-stage, atomics-free),
+// standalone GroupNorm apply, LayerNorm, row softmax.
+//
+// GroupNorm is split the MI355X way: the reduction (F.group_norm's mean/var) is its own streaming
+// pass that emits per-(image, channel) (scale, shift); the affine + SiLU is applied by the consumer
+// igemm while it stages its A operand, so the normalised tensor is never written to HBM
+// (diffusers runs norm, silu and conv as three library kernels: resnet.py ResnetBlock2D.forward).
+#include "i2i_dev.h"
+#include "launch.h"
+
+namespace {
+
+constexpr int GN_JMAX = 5;   // up to 5*64*8 = 2560 channels (UNet 2560-channel concat inputs)
+
+// lanes of a wave cover LPP 8-channel units of one pixel; 64/LPP pixels per wave step.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const i2i_gn_stats_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ct = p.c0 + p.c1, cc = ct >> 3;
+    int lpp = 64;
+    while (lpp > cc) lpp >>= 1;
+    const int ppw = 64 / lpp, jn = (cc + lpp - 1) / lpp;
+    const int lane_cp = lane & (lpp - 1), lane_px = lane / lpp;
+    const int img = blockIdx.y, part = blockIdx.x;
+    const int per = (p.hw + p.nparts - 1) / p.nparts;
+    const int px0 = part * per, px1 = min(p.hw, px0 + per);
+
+    float s[GN_JMAX][8], q[GN_JMAX][8];
+#pragma unroll
+    for (int j = 0; j < GN_JMAX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
+
+    const T* x0 = (const T*)p.x0 + (int64_t)img * p.hw * p.ld0;
+    const T* x1 = p.x1 ? (const T*)p.x1 + (int64_t)img * p.hw * p.ld1 : nullptr;
+    for (int px = px0 + wave * ppw + lane_px; px < px1; px += 4 * ppw) {
+#pragma unroll
+        for (int j = 0; j < GN_JMAX; ++j) {
+            const int cp = lane_cp + j * lpp;
+            if (j < jn && cp < cc) {
+                const int c = cp << 3;
+                const T* src = (c < p.c0) ? x0 + (int64_t)px * p.ld0 + c : x1 + (int64_t)px * p.ld1 + (c - p.c0);
+#pragma unroll
+                for (int h = 0; h < 8 / EPC; ++h) {
+                    const chunk_t v = *(const chunk_t*)(src + h * EPC);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float f = to_f32<T>(v[e]);
+                        s[j][h * EPC + e] += f;
+                        q[j][h * EPC + e] += f * f;
+                    }
+                }
+            }
+        }
+    }
+    // reduce over the pixel sub-lanes of the wave (same channel unit lives at lane_cp + m*lpp)
+#pragma unroll
+    for (int j = 0; j < GN_JMAX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int m = lpp; m < 64; m <<= 1) {
+                s[j][e] += __shfl_xor(s[j][e], m);
+                q[j][e] += __shfl_xor(q[j][e], m);
+            }
+    // cross-wave: fixed order wave 0,1,2,3 (deterministic)
+    float* chs = (float*)i2i_smem;
+    float* chq = chs + ct;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && lane_px == 0) {
+#pragma unroll
+            for (int j = 0; j < GN_JMAX; ++j) {
+                const int cp = lane_cp + j * lpp;
+                if (j < jn && cp < cc) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = (cp << 3) + e;
+                        if (w == 0) { chs[c] = s[j][e]; chq[c] = q[j][e]; }
+                        else { chs[c] += s[j][e]; chq[c] += q[j][e]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int cpg = ct / p.groups;
+    for (int g = tid; g < p.groups; g += 256) {
+        float S = 0.f, Q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += chs[c]; Q += chq[c]; }
+        float* out = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g) * 2;
+        out[0] = S;
+        out[1] = Q;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_params p) {
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const int ct = p.c0 + p.c1, cpg = ct / p.groups;
+    float* mean = (float*)i2i_smem;
+    float* rstd = mean + p.groups;
+    for (int g = tid; g < p.groups; g += 256) {
+        float S = 0.f, Q = 0.f;
+        for (int part = 0; part < p.nparts; ++part) {
+            const float* in = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g) * 2;
+            S += in[0];
+            Q += in[1];
+        }
+        const float inv = 1.0f / ((float)cpg * (float)p.hw);
+        const float mu = S * inv;
+        const float var = fmaxf(Q * inv - mu * mu, 0.f);
+        mean[g] = mu;
+        rstd[g] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < ct; c += 256) {
+        const int g = c / cpg;
+        const float sc = rstd[g] * p.gamma[c];
+        float* o = p.ss + ((int64_t)img * ct + c) * 2;
+        o[0] = sc;
+        o[1] = p.beta[c] - mean[g] * sc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const i2i_gn_apply_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int64_t nchunk = (int64_t)p.nimg * p.hw * p.c / EPC;
+    const int cpp = p.c / EPC;   // chunks per pixel
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / cpp;
+        const int c = (int)(i - pix * cpp) * EPC;
+        const int img = (int)(pix / p.hw);
+        chunk_t v = ((const chunk_t*)p.x)[i];
+        const float* ss = p.ss + ((int64_t)img * p.c + c) * 2;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float f = to_f32<T>(v[e]) * ss[2 * e] + ss[2 * e + 1];
+            if (p.act == 1) f = silu_f(f);
+            v[e] = from_f32<T>(f);
+        }
+        ((chunk_t*)p.y)[i] = v;
+    }
+}
+
+constexpr int LN_JMAX = 4;   // 4*64*8 = 2048 channels per row max
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const i2i_layernorm_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const int cc = p.c >> 3;
+    const T* x = (const T*)p.x + (int64_t)row * p.ldx;
+    float v[LN_JMAX][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_JMAX; ++j) {
+        const int cp = lane + j * 64;
+        if (cp < cc) {
+#pragma unroll
+            for (int h = 0; h < 8 / EPC; ++h) {
+                const chunk_t c = *(const chunk_t*)(x + (cp << 3) + h * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { v[j][h * EPC + e] = to_f32<T>(c[e]); sum += v[j][h * EPC + e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        }
+    }
+    const float mu = wave_sum(sum) / (float)p.c;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_JMAX; ++j) {
+        const int cp = lane + j * 64;
+        if (cp < cc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.c + p.eps);
+    T* y = (T*)p.y + (int64_t)row * p.ldy;
+#pragma unroll
+    for (int j = 0; j < LN_JMAX; ++j) {
+        const int cp = lane + j * 64;
+        if (cp < cc) {
+#pragma unroll
+            for (int h = 0; h < 8 / EPC; ++h) {
+                chunk_t c;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int ch = (cp << 3) + h * EPC + e;
+                    c[e] = from_f32<T>((v[j][h * EPC + e] - mu) * rstd * p.gamma[ch] + p.beta[ch]);
+                }
+                *(chunk_t*)(y + (cp << 3) + h * EPC) = c;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(const i2i_softmax_params p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const float* s = p.s + row * p.lds;
+    float mx = -INFINITY;
+    for (int c = lane; c < p.cols; c += 64) mx = fmaxf(mx, s[c] * p.scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < p.cols; c += 64) sum += __expf(s[c] * p.scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* o = (T*)p.p + row * p.ldp;
+    for (int c = lane; c < p.ldp; c += 64) o[c] = (c < p.cols) ? from_f32<T>(__expf(s[c] * p.scale - mx) * inv) : from_f32<T>(0.f);
+}
+
+template <typename T>
+int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
+    const int ct = p.c0 + p.c1;
+    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3((unsigned)p.nparts, (unsigned)p.nimg), dim3(256), (size_t)ct * 8, s, p);
+    int rc = i2i::check_launch("gn_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg), dim3(256), (size_t)p.groups * 8, s, p);
+    return i2i::check_launch("gn_finalize");
+}
+
+}  // namespace
+
+extern "C" int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream) {
+    if (!p || !p->x0 || !p->partial || !p->ss || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: null pointer");
+    const int ct = p->c0 + p->c1;
+    if (p->c0 % 8 || p->c1 % 8 || p->ld0 % 8 || (p->x1 && p->ld1 % 8)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: channels must be multiples of 8");
+    if (ct % p->groups || ct > GN_JMAX * 64 * 8 || p->groups > 256 || p->nparts < 1) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: bad geometry (ct=%d groups=%d)", ct, p->groups);
+    if ((p->c1 != 0) != (p->x1 != nullptr)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: x1/c1 mismatch");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case I2I_F32: return gn_stats_t<float>(*p, s);
+        case I2I_BF16: return gn_stats_t<__bf16>(*p, s);
+        case I2I_F16: return gn_stats_t<_Float16>(*p, s);
+    }
+    return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: bad dtype");
+}
+
+extern "C" int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream) {
+    if (!p || !p->x || !p->y || !p->ss) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: null pointer");
+    if (p->c % 8) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: c %% 8");
+    const int64_t n = (int64_t)p->nimg * p->hw * p->c / 8;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((gn_apply_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((gn_apply_kernel<_Float16>), dim3(grid), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: bad dtype");
+    }
+    return i2i::check_launch("gn_apply");
+}
+
+extern "C" int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream) {
+    if (!p || !p->x || !p->y || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: null pointer");
+    if (p->c % 8 || p->c > LN_JMAX * 64 * 8 || p->ldx % 8 || p->ldy % 8) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: bad c=%d", p->c);
+    const unsigned grid = (unsigned)((p->rows + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((layernorm_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((layernorm_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((layernorm_kernel<_Float16>), dim3(grid), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: bad dtype");
+    }
+    return i2i::check_launch("layernorm");
+}
+
+extern "C" int i2i_softmax(const i2i_softmax_params* p, int dtype, void* stream) {
+    if (!p || !p->s || !p->p) return i2i::fail(I2I_ERR_BAD_ARG, "softmax: null pointer");
+    if (p->cols < 1 || p->ldp < p->cols) return i2i::fail(I2I_ERR_BAD_ARG, "softmax: bad cols");
+    const unsigned grid = (unsigned)((p->rows + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((softmax_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((softmax_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((softmax_kernel<_Float16>), dim3(grid), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "softmax: bad dtype");
+    }
+    return i2i::check_launch("softmax");
+}

@@ -1,0 +1,197 @@
+/*
+ * i2i_turbo.h -- C ABI of the MI355X (gfx950) kernels behind Pix2Pix_Turbo / CycleGAN_Turbo .forward().
+ *
+ * The reference (GaParmar/img2img-turbo) has no FFI/plugin interface: its hot path
+ * (src/pix2pix_turbo.py:186-219, src/cyclegan_turbo.py:199-207, src/model.py:14-54) reaches its
+ * kernels through torch.nn.functional inside diffusers/peft.  Each entry point below names the
+ * library call(s) it replaces on that path.  All functions are `extern "C"`, take plain pointers and
+ * sizes (no torch types), never allocate device memory, never synchronise, and launch asynchronously
+ * on the caller's hipStream_t (graph-capturable).  Return value: 0 = ok, negative = error; the message
+ * is available from i2i_last_error().
+ *
+ * Activations are NHWC ("tokens" [B, H*W, C] are the same memory), element type = `dtype`.
+ * Channel counts of every activation tensor are multiples of 8 (inputs are padded once at the boundary).
+ * Weights are packed [Cout][KH][KW][Cin] (k contiguous) in `dtype`; biases and norm affine parameters
+ * are fp32.
+ */
+#ifndef I2I_TURBO_H
+#define I2I_TURBO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2I_ABI_VERSION 1
+
+typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2 } i2i_dtype;
+
+typedef enum {
+    I2I_OK = 0,
+    I2I_ERR_BAD_ARG = -1,      /* unsupported shape / alignment / null pointer */
+    I2I_ERR_LAUNCH = -2,       /* HIP reported an error at launch */
+    I2I_ERR_UNSUPPORTED = -3,
+    I2I_ERR_RUNTIME = -4       /* other HIP runtime failure (graph capture, events) */
+} i2i_status;
+
+typedef enum {
+    I2I_OP_IGEMM = 1,
+    I2I_OP_GN_STATS = 2,
+    I2I_OP_LAYERNORM = 3,
+    I2I_OP_SOFTMAX = 4,
+    I2I_OP_NCHW_TO_NHWC = 5,
+    I2I_OP_NHWC_TO_NCHW = 6,
+    I2I_OP_POSTERIOR = 7,
+    I2I_OP_DDPM_POSTQUANT = 8,
+    I2I_OP_ATTENTION = 9,
+    I2I_OP_GN_APPLY = 10
+} i2i_opcode;
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear / batched matmul on MFMA.
+ *   C[m][n] = epilogue( alpha * sum_k A[m][k] * B[n][k] )
+ * Replaces F.conv2d (3x3 s1/s2, 1x1), F.linear and the q.k^T / p.v matmuls of
+ * F.scaled_dot_product_attention, with the surrounding F.group_norm+F.silu (as an A-operand
+ * prologue), F.interpolate(nearest 2x) and torch.cat (as A-operand gathers), F.pad(0,1,0,1), bias,
+ * residual add, skip add (src/model.py:41-43) and GEGLU fused in.  LoRA (peft) is merged into B at
+ * load (W' = W + s.B.A), so one launch covers base + adapter.
+ *
+ * A operand: virtual concat of up to two NHWC sources [nimg][hin][win][c0 | c1]; m -> (img, oy, ox),
+ *            k -> (ky, kx, ci); input coord = (o*stride + k - pad) >> ups, zero outside.
+ *            z (grid z) adds zb*a_bs_b + zh*a_bs_h with zb = z / zh_count, zh = z % zh_count.
+ * B operand: [N][ldb] k-contiguous (weights, or K of q.k^T, or V^T of p.v).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* a0; const void* a1;
+    int32_t c0, c1;            /* channels per source (c1 = 0: single source); multiples of 8 */
+    int32_t lda0, lda1;        /* pixel stride in elements (>= c0 / c1, multiple of 8) */
+    int64_t a_bs_b, a_bs_h;    /* batch strides (elements) applied to BOTH sources */
+    int32_t nimg, hin, win;    /* source geometry (before the optional 2x upsample) */
+    int32_t ho, wo;            /* output geometry; M = nimg*ho*wo */
+    int32_t ks, stride, pad, ups;
+    const void* b; int32_t ldb; int64_t b_bs_b, b_bs_h;
+    int32_t M, N, K;           /* K = ks*ks*(c0+c1) */
+    const float* gn_ss;        /* optional [nimg][c0+c1][2] = (scale, shift) from I2I_OP_GN_STATS */
+    int32_t act;               /* 0 none, 1 SiLU (after the affine) */
+    const float* bias; int32_t bias_mode;   /* 0 none, 1 per column n, 2 per row m */
+    float alpha;
+    const void* res; int32_t ldr; int64_t r_bs_b, r_bs_h;   /* optional residual, same dtype */
+    void* c; int32_t ldc; int64_t c_bs_b, c_bs_h;
+    int32_t zcount, zh_count;  /* grid z = zcount batches; zh_count heads per batch (>= 1) */
+    int32_t geglu;             /* 1: B rows interleaved [a16|g16]; out[:, n/2] = a * gelu(g); ldc for N/2 */
+    int32_t out_f32;           /* 1: store fp32 regardless of dtype (attention scores) */
+    int32_t tile;              /* 0 = auto; else forces a tile config id (tests / tuning) */
+} i2i_igemm_params;
+
+/* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.
+ * Replaces the reduction half of F.group_norm; the affine+SiLU half runs in the consumer's prologue.
+ * Two-stage and atomics-free (deterministic).  `partial` needs nimg*nparts*groups*2 floats. */
+typedef struct {
+    const void* x0; const void* x1; int32_t c0, c1, ld0, ld1;
+    int32_t nimg, hw, groups; float eps;
+    const float* gamma; const float* beta;    /* [c0+c1] fp32 */
+    float* partial; int32_t nparts;
+    float* ss;                                /* out [nimg][c0+c1][2] */
+} i2i_gn_stats_params;
+
+/* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Fallback used when fusion is disabled. */
+typedef struct {
+    const void* x; void* y; const float* ss; int32_t nimg, hw, c, act;
+} i2i_gn_apply_params;
+
+/* LayerNorm over the last dim (F.layer_norm, eps 1e-5, affine). rows x c, c multiple of 8. */
+typedef struct {
+    const void* x; void* y; const float* gamma; const float* beta; int32_t rows, c, ldx, ldy; float eps;
+} i2i_layernorm_params;
+
+/* Row softmax of fp32 scores: p = softmax(scale * s) written as `dtype` with zero padding up to ldp.
+ * The softmax step of F.scaled_dot_product_attention on the unfused path. */
+typedef struct {
+    const float* s; void* p; int64_t rows; int32_t cols, lds, ldp; float scale;
+} i2i_softmax_params;
+
+/* Fused flash-style attention (F.scaled_dot_product_attention, no mask, not causal).
+ * q [b][tq][ldq] / k [b][tk][ldk] with head h at column h*d; vt is V^T: [b][heads*d][ldvt] (tk contiguous). */
+typedef struct {
+    const void* q; const void* k; const void* vt; void* o;
+    int32_t batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo;
+    int64_t q_bs, k_bs, vt_bs, o_bs; float scale;
+} i2i_attention_params;
+
+/* Boundary layout ops.  NCHW fp32/`dtype` <-> NHWC `dtype` with channel padding (zeros). */
+typedef struct {
+    const void* x; void* y; int32_t n, c, h, w, cpad; int32_t src_dtype; float mul, add;
+} i2i_nchw_to_nhwc_params;
+typedef struct {
+    const void* x; void* y; int32_t n, c, h, w, ldx; int32_t dst_dtype; int32_t clamp; /* clamp to [-1,1] */
+} i2i_nhwc_to_nchw_params;
+
+/* DiagonalGaussianDistribution.sample() * scaling_factor (+ stochastic mix, src/pix2pix_turbo.py:210):
+ * z = (mean + exp(.5*clamp(logvar,-30,20)) * eps) * sf ; u = z*r + noise*(1-r)  (r = 1 => u = z).
+ * moments NHWC [n][hw][ldm] (mean = ch 0..lat-1, logvar = lat..2lat-1); eps/noise NCHW fp32 [n][lat][hw]
+ * (noise may have n = 1 and is broadcast); u NHWC padded to ldu channels (zeros). */
+typedef struct {
+    const void* moments; const float* eps; const float* noise; void* u;
+    int32_t n, hw, lat, ldm, ldu, noise_n; float sf, r;
+    float* u_f32;      /* optional fp32 copy [n][hw][lat] for the scheduler step (keeps latent math fp32) */
+    int32_t moments_f32; /* 1: moments are fp32 (producer igemm stored with out_f32) */
+} i2i_posterior_params;
+
+/* DDPMScheduler.step at the single timestep + /scaling_factor + post_quant_conv (1x1, lat x lat):
+ * x0 = (u - sqrt(1-abar)*e)/sqrt(abar) ; y = Wpq.(x0/sf) + bpq.  All fp32 in registers. */
+typedef struct {
+    const void* u; const void* e; void* y; const float* wpq; const float* bpq;
+    int32_t n, hw, lat, ldu, lde, ldy; float sqrt_abar, sqrt_1m_abar, sf;
+    int32_t u_f32, e_f32;  /* 1: that operand is fp32 (ldu/lde in fp32 elements) */
+} i2i_ddpm_params;
+
+typedef struct {
+    int32_t opcode;    /* i2i_opcode */
+    int32_t dtype;     /* i2i_dtype */
+    union {
+        i2i_igemm_params igemm;
+        i2i_gn_stats_params gn_stats;
+        i2i_gn_apply_params gn_apply;
+        i2i_layernorm_params layernorm;
+        i2i_softmax_params softmax;
+        i2i_attention_params attention;
+        i2i_nchw_to_nhwc_params to_nhwc;
+        i2i_nhwc_to_nchw_params to_nchw;
+        i2i_posterior_params posterior;
+        i2i_ddpm_params ddpm;
+    } u;
+} i2i_op;
+
+/* ---- library ---- */
+int i2i_abi_version(void);
+const char* i2i_backend(void);            /* "gfx950" (product) */
+const char* i2i_last_error(void);
+size_t i2i_sizeof_op(void);               /* sanity check for FFI struct layout */
+
+/* ---- single-op entry points (each = one or two kernel launches on `stream`) ---- */
+int i2i_igemm(const i2i_igemm_params* p, int dtype, void* stream);
+int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);
+int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream);
+int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream);
+int i2i_softmax(const i2i_softmax_params* p, int dtype, void* stream);
+int i2i_attention(const i2i_attention_params* p, int dtype, void* stream);
+int i2i_nchw_to_nhwc(const i2i_nchw_to_nhwc_params* p, int dtype, void* stream);
+int i2i_nhwc_to_nchw(const i2i_nhwc_to_nchw_params* p, int dtype, void* stream);
+int i2i_posterior(const i2i_posterior_params* p, int dtype, void* stream);
+int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream);
+
+/* ---- programs: a forward pass is a flat array of ops executed in order on one stream ---- */
+int i2i_run(const i2i_op* ops, int n_ops, void* stream);
+/* Same, with a hipEvent pair around every op; ms[i] = duration of op i (synchronises at the end). */
+int i2i_run_timed(const i2i_op* ops, int n_ops, void* stream, float* ms);
+/* Capture the program into a hipGraph (launch-bound bs=1 path) and replay it. */
+int i2i_graph_create(const i2i_op* ops, int n_ops, void** graph_out);
+int i2i_graph_launch(void* graph, void* stream);
+int i2i_graph_destroy(void* graph);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2I_TURBO_H */

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "slow: multi-second CPU test")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """CPU emulator twin of the HIP library (tests/emu/): same kernel sources, host clang."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from img2img_turbo_amd import _capi
+    lib = _capi.Library(build_emu.build())
+    assert lib.backend == "emu"
+    return lib
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library on a real GPU; fails loudly (no fallback) if the HIP build is missing."""
+    import torch
+    from img2img_turbo_amd import _capi
+    assert torch.cuda.is_available(), "gpu-marked test without a GPU"
+    lib = _capi.default_library()
+    assert lib.backend == "gfx950"
+    return lib

@@ -1,0 +1,56 @@
+"""Build the CPU emulator twin of libi2i_turbo.so from the SAME kernel sources (test infrastructure).
+
+    python tests/emu/build_emu.py
+
+Host clang compiles img2img-turbo_amd/csrc/*.hip as plain C++ with tests/emu/hip_emu.h force-included.
+Output: tests/emu/build/libi2i_turbo_emu.so (git-ignored).  Never loaded by the product.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SOURCES = ["igemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "capi.hip"]
+OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
+FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
+         "-Wno-unused-function", "-Wno-unknown-attributes"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _cc(src_path, obj, lang_cxx):
+    deps = [src_path, os.path.join(HERE, "hip_emu.h"), os.path.join(CSRC, "i2i_dev.h"), os.path.join(CSRC, "launch.h"),
+            os.path.join(ROOT, "include", "i2i_turbo.h")]
+    if _stale(obj, deps):
+        cmd = [CLANG] + FLAGS + (["-x", "c++"] if lang_cxx else []) + ["-c", src_path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emu compile failed for %s:\n%s" % (src_path, r.stderr))
+    return obj
+
+
+def build():
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    jobs = [(os.path.join(CSRC, s), os.path.join(HERE, "build", s.replace(".hip", ".emu.o")), True) for s in SOURCES]
+    jobs += [(os.path.join(HERE, "hip_emu.cpp"), os.path.join(HERE, "build", "hip_emu.o"), False),
+             (os.path.join(HERE, "runtime_emu.cpp"), os.path.join(HERE, "build", "runtime_emu.o"), False)]
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(lambda j: _cc(*j), jobs))
+    if _stale(OUT, objs):
+        r = subprocess.run([CLANG, "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emu link failed:\n" + r.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build())

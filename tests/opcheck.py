@@ -1,0 +1,294 @@
+"""Per-op parity checks shared by the CPU-emulator tests and the GPU tests.
+
+Each check builds seeded inputs, runs ONE op of the HIP library through the C ABI
+(``_capi.Library`` -- the real gfx950 build on a GPU box, the emulator twin on the CPU) and compares with
+a plain PyTorch fp32 statement of the same op (the building blocks of oracle/nn.py).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from img2img_turbo_amd import _capi as K
+from img2img_turbo_amd import ops as O
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2, torch.float16: 6e-3}
+
+
+def run_op(lib, opcode, params, dtype, device):
+    prog = K.Program()
+    prog.add(opcode, O.DT[dtype], params)
+    prog.freeze()
+    stream = torch.cuda.current_stream().cuda_stream if device != "cpu" else 0
+    lib.run(prog, stream)
+    if device != "cpu":
+        torch.cuda.synchronize()
+
+
+def pack_conv_weight(w, dtype, cpad=None):
+    """OIHW -> [O][KH*KW*Ipad] (k = (ky,kx,ci), ci contiguous)."""
+    o, i, kh, kw = w.shape
+    ip = cpad or ((i + 7) // 8 * 8)
+    wp = torch.zeros(o, kh, kw, ip, dtype=torch.float32)
+    wp[..., :i] = w.permute(0, 2, 3, 1)
+    return wp.reshape(o, kh * kw * ip).to(dtype).contiguous()
+
+
+def nhwc(x, dtype, cpad=None):
+    n, c, h, w = x.shape
+    cp = cpad or ((c + 7) // 8 * 8)
+    y = torch.zeros(n, h, w, cp, dtype=torch.float32)
+    y[..., :c] = x.permute(0, 2, 3, 1)
+    return y.to(dtype).contiguous()
+
+
+def rel_err(got, ref):
+    return float((got.float() - ref.float()).abs().max() / (ref.float().abs().max() + 1e-12))
+
+
+def gn_scale_shift(x, groups, gamma, beta, eps):
+    """fp32 reference of the (scale, shift) pairs i2i_gn_stats must produce. x: NCHW."""
+    n, c, h, w = x.shape
+    xg = x.reshape(n, groups, -1)
+    mean = xg.mean(-1)
+    var = xg.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    cpg = c // groups
+    sc = rstd.repeat_interleave(cpg, 1) * gamma[None]
+    sh = beta[None] - mean.repeat_interleave(cpg, 1) * sc
+    return torch.stack([sc, sh], -1).contiguous()  # [n][c][2]
+
+
+def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, stride=1, pad=1, ups=0,
+               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4):
+    g = torch.Generator().manual_seed(seed)
+    ct = cin + cin2
+    x = torch.randn(n, ct, h, w, generator=g)
+    wt = torch.randn(cout, ct, ks, ks, generator=g) / math.sqrt(ct * ks * ks)
+    b = torch.randn(cout, generator=g) * 0.1 if bias else None
+    xin = x.to(dtype).float()  # what the kernel sees
+    ref_in = xin
+    ss = None
+    if gn:
+        gamma = 1 + 0.1 * torch.randn(ct, generator=g)
+        beta = 0.1 * torch.randn(ct, generator=g)
+        ss = gn_scale_shift(xin, groups, gamma, beta, 1e-5)
+        ref_in = xin * ss[:, :, 0][:, :, None, None] + ss[:, :, 1][:, :, None, None]
+        if act:
+            ref_in = F.silu(ref_in)
+        ref_in = ref_in.to(dtype).float()  # kernel rounds the transformed operand to dtype
+    if ups:
+        ref_in = F.interpolate(ref_in, scale_factor=2.0, mode="nearest")
+    wq = wt.to(dtype).float()
+    if asym_pad:
+        ref = F.conv2d(F.pad(ref_in, (0, 1, 0, 1)), wq, b, stride=stride)
+        kpad = 0
+    else:
+        ref = F.conv2d(ref_in, wq, b, stride=stride, padding=pad)
+        kpad = pad
+    ref = ref * alpha if b is None else (ref - b[None, :, None, None]) * alpha + b[None, :, None, None]
+    ho, wo = ref.shape[-2:]
+    r = None
+    if res:
+        r = torch.randn(n, cout, ho, wo, generator=g)
+        ref = ref + r.to(dtype).float()
+    # device tensors
+    x0 = nhwc(x[:, :cin], dtype).to(device)
+    x1 = nhwc(x[:, cin:], dtype).to(device) if cin2 else None
+    # weights: k = (ky,kx,[c0 | c1]) with each source padded to 8
+    c0p = x0.shape[-1]
+    c1p = x1.shape[-1] if cin2 else 0
+    wp = torch.zeros(cout, ks, ks, c0p + c1p)
+    wp[..., :cin] = wt[:, :cin].permute(0, 2, 3, 1)
+    if cin2:
+        wp[..., c0p:c0p + cin2] = wt[:, cin:].permute(0, 2, 3, 1)
+    wp = wp.reshape(cout, -1).to(dtype).contiguous().to(device)
+    ssd = None
+    if gn:
+        ssp = torch.zeros(n, c0p + c1p, 2)
+        ssp[:, :cin] = ss[:, :cin]
+        if cin2:
+            ssp[:, c0p:c0p + cin2] = ss[:, cin:]
+        ssd = ssp.contiguous().to(device)
+    coutp = (cout + 7) // 8 * 8
+    out = torch.full((n, ho, wo, coutp), float("nan"), dtype=dtype, device=device)
+    rd = nhwc(r, dtype, coutp).to(device) if res else None
+    bd = b.float().to(device) if bias else None
+    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=ks, stride=stride, pad=kpad, ups=ups,
+                       x1=x1, c0=c0p, c1=c1p, N=cout, gn_ss=ssd, act=act, bias=bd, alpha=alpha, res=rd, tile=tile)
+    run_op(lib, opcode, p, dtype, device)
+    got = out.cpu().float()[..., :cout].permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all(), "non-finite output"
+    err = rel_err(got, ref)
+    assert err < TOL[dtype], f"conv rel err {err}"
+    return err
+
+
+def check_geglu(lib, device, dtype, *, rows=70, cin=32, cff=64, seed=0, tile=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(2 * cff, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(2 * cff, generator=g) * 0.1
+    xq, wq = x.to(dtype).float(), w.to(dtype).float()
+    hgl = F.linear(xq, wq, b)
+    a, gt = hgl.chunk(2, -1)
+    ref = a * F.gelu(gt)
+    # interleave rows per 16: [a 16][g 16]
+    idx = []
+    for j in range(cff // 16):
+        idx += list(range(16 * j, 16 * j + 16)) + list(range(cff + 16 * j, cff + 16 * j + 16))
+    idx = torch.tensor(idx)
+    wp = w[idx].to(dtype).contiguous().to(device)
+    bp = b[idx].float().contiguous().to(device)
+    xd = x.to(dtype).contiguous().to(device)
+    out = torch.full((rows, cff), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.conv(xd, wp, out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, bias=bp, geglu=1, ldc=cff, tile=tile)
+    run_op(lib, opcode, p, dtype, device)
+    err = rel_err(out.cpu(), ref)
+    assert err < TOL[dtype], f"geglu rel err {err}"
+    return err
+
+
+def check_bgemm(lib, device, dtype, *, batch=2, heads=2, M=40, N=24, Kd=64, out_f32=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    C = heads * Kd
+    a = torch.randn(batch, M, C, generator=g).to(dtype)
+    b = torch.randn(batch, N, C, generator=g).to(dtype)
+    ref = torch.einsum("bmhk,bnhk->bhmn", a.float().view(batch, M, heads, Kd), b.float().view(batch, N, heads, Kd)) * 0.5
+    ad, bd = a.to(device), b.to(device)
+    out = torch.full((batch, heads, M, N), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=device)
+    opcode, p = O.bgemm(ad, bd, out, M=M, N=N, Kdim=Kd, lda=C, ldb=C, ldc=N, batch=batch, heads=heads,
+                        a_bs=(M * C, Kd), b_bs=(N * C, Kd), c_bs=(heads * M * N, M * N), alpha=0.5, out_f32=out_f32)
+    run_op(lib, opcode, p, dtype, device)
+    err = rel_err(out.cpu(), ref)
+    assert err < TOL[dtype], f"bgemm rel err {err}"
+    return err
+
+
+def check_gn_stats(lib, device, dtype, *, n=2, c0=32, c1=0, h=9, w=7, groups=8, nparts=3, eps=1e-5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ct = c0 + c1
+    x = torch.randn(n, ct, h, w, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.1 * torch.randn(ct, generator=g)
+    beta = 0.1 * torch.randn(ct, generator=g)
+    xq = x.to(dtype).float()
+    ref = gn_scale_shift(xq, groups, gamma, beta, eps)
+    x0 = nhwc(x[:, :c0], dtype).to(device)
+    x1 = nhwc(x[:, c0:], dtype).to(device) if c1 else None
+    partial = torch.zeros(n * nparts * groups * 2, device=device)
+    ss = torch.full((n, ct, 2), float("nan"), device=device)
+    opcode, p = O.gn_stats(x0, gamma.to(device), beta.to(device), partial, ss, nimg=n, hw=h * w, groups=groups, eps=eps,
+                           nparts=nparts, x1=x1, c0=c0, c1=c1)
+    run_op(lib, opcode, p, dtype, device)
+    err = rel_err(ss.cpu(), ref)
+    assert err < 1e-4, f"gn_stats rel err {err}"
+    return err
+
+
+def check_layernorm(lib, device, dtype, *, rows=9, c=320, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, c, generator=g) * 2 + 0.5
+    gamma = 1 + 0.1 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    ref = F.layer_norm(x.to(dtype).float(), (c,), gamma, beta, 1e-5)
+    xd = x.to(dtype).to(device)
+    y = torch.full((rows, c), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.layernorm(xd, y, gamma.to(device), beta.to(device), rows=rows, c=c)
+    run_op(lib, opcode, p, dtype, device)
+    err = rel_err(y.cpu(), ref)
+    assert err < TOL[dtype], f"layernorm rel err {err}"
+    return err
+
+
+def check_softmax(lib, device, dtype, *, rows=11, cols=77, ldp=80, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(rows, cols, generator=g) * 4
+    ref = torch.softmax(s * 0.125, -1)
+    sd = s.to(device)
+    pout = torch.full((rows, ldp), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.softmax(sd, pout, rows=rows, cols=cols, lds=cols, ldp=ldp, scale=0.125)
+    run_op(lib, opcode, p, dtype, device)
+    got = pout.cpu().float()
+    assert (got[:, cols:] == 0).all()
+    err = rel_err(got[:, :cols], ref)
+    assert err < TOL[dtype], f"softmax rel err {err}"
+    return err
+
+
+def check_attention(lib, device, dtype, *, batch=2, heads=2, tq=70, tk=77, d=64, seed=0, spike=False):
+    g = torch.Generator().manual_seed(seed)
+    C = heads * d
+    q = torch.randn(batch, tq, C, generator=g).to(dtype)
+    k = torch.randn(batch, tk, C, generator=g).to(dtype)
+    v = torch.randn(batch, tk, C, generator=g).to(dtype)
+    if spike:  # force a late running-max jump (rescale branch) on one query
+        k[0, tk - 3, :d] = q[0, 5, :d] * 3
+    qf, kf, vf = (t.float().view(batch, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(d), -1) @ vf
+    ref = ref.transpose(1, 2).reshape(batch, tq, C)
+    epc = 4 if dtype == torch.float32 else 8
+    ldvt = (tk + epc - 1) // epc * epc
+    vt = torch.full((batch, C, ldvt), float("nan"), dtype=dtype)  # padding deliberately poisoned
+    vt[:, :, :tk] = v.transpose(1, 2)
+    qd, kd, vtd = q.to(device), k.to(device), vt.to(device)
+    o = torch.full((batch, tq, C), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.attention(qd, kd, vtd, o, batch=batch, heads=heads, d=d, tq=tq, tk=tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
+                            q_bs=tq * C, k_bs=tk * C, vt_bs=C * ldvt, o_bs=tq * C, scale=1.0 / math.sqrt(d))
+    run_op(lib, opcode, p, dtype, device)
+    got = o.cpu()
+    assert torch.isfinite(got.float()).all()
+    err = rel_err(got, ref)
+    assert err < TOL[dtype], f"attention rel err {err}"
+    return err
+
+
+def check_boundary(lib, device, dtype, *, n=2, h=6, w=10, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 3, h, w, generator=g)
+    y = torch.full((n, h, w, 8), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.nchw_to_nhwc(x.to(device), y, n=n, c=3, h=h, w=w, cpad=8, mul=2.0, add=-1.0)
+    run_op(lib, opcode, p, dtype, device)
+    ref = nhwc(x * 2 - 1, dtype)
+    assert torch.equal(y.cpu().float(), ref.float())
+    # back
+    t = (torch.randn(n, h, w, 8, generator=g) * 1.5).to(dtype)
+    out = torch.full((n, 3, h, w), float("nan"), dtype=torch.float32, device=device)
+    opcode, p = O.nhwc_to_nchw(t.to(device), out, n=n, c=3, h=h, w=w, ldx=8, clamp=1)
+    run_op(lib, opcode, p, dtype, device)
+    assert torch.equal(out.cpu(), t.float()[..., :3].permute(0, 3, 1, 2).clamp(-1, 1))
+    return 0.0
+
+
+def check_latent_ops(lib, device, dtype, *, n=2, h=4, w=6, seed=0, r=0.4):
+    g = torch.Generator().manual_seed(seed)
+    hw, lat = h * w, 4
+    moments = torch.randn(n, 2 * lat, h, w, generator=g)
+    eps = torch.randn(n, lat, h, w, generator=g)
+    noise = torch.randn(1, lat, h, w, generator=g)
+    mean, logvar = moments.chunk(2, 1)
+    z = (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * eps) * 0.18215
+    u_ref = z * r + noise * (1 - r)
+    md = moments.permute(0, 2, 3, 1).contiguous().to(device)  # fp32 NHWC moments
+    u = torch.full((n, hw, 8), float("nan"), dtype=dtype, device=device)
+    u32 = torch.full((n, hw, lat), float("nan"), device=device)
+    opcode, p = O.posterior(md, eps.to(device), u, n=n, hw=hw, lat=lat, ldm=2 * lat, ldu=8, sf=0.18215, r=r,
+                            noise=noise.to(device), noise_n=1, u_f32=u32, moments_f32=1)
+    run_op(lib, opcode, p, dtype, device)
+    ref_nhwc = u_ref.permute(0, 2, 3, 1).reshape(n, hw, lat)
+    assert rel_err(u32.cpu(), ref_nhwc) < 1e-5
+    assert rel_err(u.cpu()[..., :lat], ref_nhwc) < TOL[dtype]
+    assert (u.cpu().float()[..., lat:] == 0).all()
+    # ddpm + post_quant
+    e = torch.randn(n, hw, lat, generator=g)
+    wpq = torch.randn(lat, lat, generator=g) * 0.5
+    bpq = torch.randn(lat, generator=g) * 0.1
+    sa, s1 = 0.06826489, 0.99766723
+    x0 = (ref_nhwc - s1 * e) / sa / 0.18215
+    ref = x0 @ wpq.t() + bpq
+    y = torch.full((n, hw, 8), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.ddpm_postquant(u32, e.to(device), y, wpq.to(device), bpq.to(device), n=n, hw=hw, lat=lat, ldu=lat, lde=lat, ldy=8,
+                                 sqrt_abar=sa, sqrt_1m_abar=s1, sf=0.18215, u_f32=1, e_f32=1)
+    run_op(lib, opcode, p, dtype, device)
+    err = rel_err(y.cpu()[..., :lat], ref)
+    assert err < max(TOL[dtype], 1e-4) and (y.cpu().float()[..., lat:] == 0).all()
+    return err

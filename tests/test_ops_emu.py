@@ -1,0 +1,102 @@
+"""Kernel-logic parity on the CPU: the HIP kernel sources compiled for the wave-level emulator
+(tests/emu/) vs plain PyTorch fp32 statements of each op.  Small shapes; every tile config, gather mode
+and epilogue of the implicit-GEMM kernel is exercised."""
+import pytest
+import torch
+
+import opcheck as oc
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_basic(emu_lib, dtype):
+    oc.check_conv(emu_lib, "cpu", dtype)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv3x3_tiles(emu_lib, tile):
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, cout=40, tile=tile, n=1, h=9, w=11)
+
+
+def test_conv_gn_silu_prologue(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, gn=True, act=1, n=3, h=6, w=6, cin=16)   # tiles span images
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, gn=True, act=1)
+    oc.check_conv(emu_lib, "cpu", torch.float32, gn=True, act=0, ks=1, pad=0)              # transformer entry GN
+
+
+def test_conv_stride2_variants(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, stride=2, pad=1, h=12, w=8)                  # UNet downsample
+    oc.check_conv(emu_lib, "cpu", torch.float32, stride=2, asym_pad=True, h=12, w=8)          # VAE F.pad(0,1,0,1)
+
+
+def test_conv_upsample_gather(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, ups=1, h=5, w=6)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, ups=1, h=5, w=6)
+
+
+def test_conv_concat_two_sources(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, cin=16, cin2=24, gn=True, act=1, groups=5)   # group straddles the seam
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, cin=16, cin2=8)
+
+
+def test_conv_small_channels(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, cin=3, cout=32)      # VAE conv_in (padded to 8)
+    oc.check_conv(emu_lib, "cpu", torch.float32, cin=32, cout=3)      # VAE conv_out
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, cin=4, cout=4, ks=1, pad=0)
+
+
+def test_conv1x1_residual_alpha(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, ks=1, pad=0, bias=False, res=True, alpha=0.4)  # skip conv + add
+    oc.check_conv(emu_lib, "cpu", torch.float32, res=True)                                        # resnet conv2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu(emu_lib, dtype):
+    oc.check_geglu(emu_lib, "cpu", dtype)
+
+
+def test_geglu_tiles(emu_lib):
+    for tile in (1, 2, 3, 5):
+        oc.check_geglu(emu_lib, "cpu", torch.float32, tile=tile, cff=128)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bgemm(emu_lib, dtype):
+    oc.check_bgemm(emu_lib, "cpu", dtype)
+    oc.check_bgemm(emu_lib, "cpu", dtype, out_f32=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gn_stats(emu_lib, dtype):
+    oc.check_gn_stats(emu_lib, "cpu", dtype)
+    oc.check_gn_stats(emu_lib, "cpu", dtype, c0=40, c1=24, groups=4, h=5, w=5, nparts=2)      # two sources, cc=8
+    oc.check_gn_stats(emu_lib, "cpu", dtype, c0=320, groups=32, h=3, w=3, nparts=1)           # cc=40: lpp=32, jn=2
+
+
+def test_gn_stats_wide(emu_lib):
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=1280, c1=640, groups=32, h=2, w=2, nparts=1, n=1)  # 1920 ch, cpg 60
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm(emu_lib, dtype):
+    oc.check_layernorm(emu_lib, "cpu", dtype)
+    oc.check_layernorm(emu_lib, "cpu", dtype, c=1280, rows=5)
+    oc.check_layernorm(emu_lib, "cpu", dtype, c=64, rows=4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax(emu_lib, dtype):
+    oc.check_softmax(emu_lib, "cpu", dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention(emu_lib, dtype):
+    oc.check_attention(emu_lib, "cpu", dtype)
+    oc.check_attention(emu_lib, "cpu", dtype, tq=64, tk=128, batch=1, heads=1, spike=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_boundary_and_latent_ops(emu_lib, dtype):
+    oc.check_boundary(emu_lib, "cpu", dtype)
+    oc.check_latent_ops(emu_lib, "cpu", dtype)

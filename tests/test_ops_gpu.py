@@ -1,0 +1,64 @@
+"""Per-op parity on a real MI355X: the hipcc-built library through the C ABI vs PyTorch fp32 (CPU) of the
+same op.  Same checks as tests/test_ops_emu.py at larger, tile-filling shapes."""
+import pytest
+import torch
+
+import opcheck as oc
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3(gpu_lib, dtype):
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=40, w=48)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=64, cout=256, h=33, w=17, gn=True, act=1, groups=32, res=True)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv_tiles(gpu_lib, tile):
+    oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=1, cin=64, cout=72, h=24, w=24, tile=tile)
+    oc.check_conv(gpu_lib, "cuda", torch.float32, n=1, cin=64, cout=72, h=24, w=24, tile=tile)
+
+
+def test_conv_gathers(gpu_lib):
+    for dt in (torch.float32, torch.bfloat16):
+        oc.check_conv(gpu_lib, "cuda", dt, stride=2, pad=1, h=32, w=32, cin=64, cout=64)
+        oc.check_conv(gpu_lib, "cuda", dt, stride=2, asym_pad=True, h=32, w=32, cin=64, cout=64)
+        oc.check_conv(gpu_lib, "cuda", dt, ups=1, h=16, w=16, cin=64, cout=64)
+        oc.check_conv(gpu_lib, "cuda", dt, cin=64, cin2=128, gn=True, act=1, groups=32, h=16, w=16, cout=128)
+        oc.check_conv(gpu_lib, "cuda", dt, cin=3, cout=128, h=32, w=32)
+        oc.check_conv(gpu_lib, "cuda", dt, cin=128, cout=3, h=32, w=32)
+        oc.check_conv(gpu_lib, "cuda", dt, ks=1, pad=0, bias=False, res=True, alpha=0.4, cin=128, cout=256, h=16, w=16)
+        oc.check_conv(gpu_lib, "cuda", dt, n=5, cin=32, cout=64, h=4, w=4, gn=True, act=1, groups=8)  # tiles span images
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu_bgemm(gpu_lib, dtype):
+    oc.check_geglu(gpu_lib, "cuda", dtype, rows=300, cin=320, cff=1280)
+    oc.check_bgemm(gpu_lib, "cuda", dtype, batch=2, heads=5, M=256, N=256, Kd=64)
+    oc.check_bgemm(gpu_lib, "cuda", dtype, batch=1, heads=1, M=300, N=200, Kd=512, out_f32=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms(gpu_lib, dtype):
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=2, c0=128, h=64, w=64, groups=32, nparts=16)
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=2, c0=1280, c1=640, h=8, w=8, groups=32, nparts=2)
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=1, c0=320, h=16, w=16, groups=32, nparts=4)
+    oc.check_layernorm(gpu_lib, "cuda", dtype, rows=1000, c=1280)
+    oc.check_layernorm(gpu_lib, "cuda", dtype, rows=77, c=320)
+    oc.check_softmax(gpu_lib, "cuda", dtype, rows=500, cols=1024, ldp=1024)
+    oc.check_softmax(gpu_lib, "cuda", dtype, rows=500, cols=77, ldp=80)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention(gpu_lib, dtype):
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=5, tq=1024, tk=1024)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=10, tq=256, tk=77)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=1, tq=100, tk=200, spike=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_boundary_and_latent_ops(gpu_lib, dtype):
+    oc.check_boundary(gpu_lib, "cuda", dtype, n=2, h=64, w=48)
+    oc.check_latent_ops(gpu_lib, "cuda", dtype, n=3, h=16, w=16)
