@@ -1,0 +1,170 @@
+"""Pix2Pix_Turbo with the reference's API surface (src/pix2pix_turbo.py:29-229), MI355X-native inside.
+
+``forward(c_t, prompt=None, prompt_tokens=None, deterministic=True, r=1.0, noise_map=None)`` keeps the
+reference signature and semantics (:186-219).  Differences, all explicit:
+  * weights come from local files / in-memory state dicts (no HTTP download, :48-64);
+  * the LoRA scale / skip gamma / TwinConv blend ``r`` are per-call arguments of the planned program, so a
+    stochastic call does not leave state behind (reference quirk: :206-207,217 persist);
+  * a single prompt is broadcast over the batch (reference: shape error for B>1);
+  * the two RNG draws (posterior eps :198, scheduler noise :200) are drawn with torch on the device in the
+    same order; ``eps`` may also be injected for parity tests;
+  * text conditioning: pass ``caption_enc`` ([1|B,77,1024]) or give the model a ``text_encoder`` /
+    ``tokenizer`` pair (CLIP weights are not available offline).
+All arithmetic runs in the HIP kernels behind include/i2i_turbo.h; there is no torch/diffusers fallback.
+"""
+from typing import Optional
+
+import torch
+
+from . import _capi
+from .model import make_1step_sched
+from .plan import ForwardPlan
+from .packer import Packer
+from .weights import GeneratorWeights, from_pix2pix_checkpoint, load_checkpoint_file, load_sd_turbo_base
+
+
+class TurboGeneratorBase(torch.nn.Module):
+    """Shared plumbing: plan cache, packer cache, boundary staging, text conditioning."""
+
+    def __init__(self, weights: GeneratorWeights, device="cuda", dtype=torch.float32, lib=None,
+                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True):
+        super().__init__()
+        self.weights = weights
+        self.device_ = torch.device(device)
+        self.dtype_ = dtype
+        self.lib = lib or _capi.default_library()     # raises if the HIP build is missing: no fallback
+        if self.lib.backend == "gfx950" and self.device_.type != "cuda":
+            raise _capi.I2IError("the gfx950 kernel library needs a CUDA/HIP device, got %s" % device)
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.sched = make_1step_sched()
+        self.timesteps = self.sched.timesteps
+        self.use_graph = use_graph and self.lib.backend == "gfx950"
+        self.fuse_gn, self.flash = fuse_gn, flash
+        self._plans = {}
+        self._packers = {}
+        self._caption_cache = {}
+
+    # ---- reference-compatible no-ops / switches ----
+    def set_eval(self):
+        return self.eval()
+
+    def set_train(self):
+        raise NotImplementedError("training (autograd through the generator) is out of scope of the MI355X forward path")
+
+    def half(self):
+        return self.to_dtype(torch.float16)
+
+    def bfloat16(self):
+        return self.to_dtype(torch.bfloat16)
+
+    def float(self):
+        return self.to_dtype(torch.float32)
+
+    def to_dtype(self, dtype):
+        if dtype != self.dtype_:
+            self.dtype_ = dtype
+            self._plans.clear()
+            self._packers.clear()
+        return self
+
+    # ---- plumbing ----
+    def _get_packers(self, r, direction):
+        key = (self.dtype_, round(float(r), 6), direction)
+        if key not in self._packers:
+            w = self.weights
+            vae_sd = w.vae if (direction == "a2b" or w.vae_b2a is None) else w.vae_b2a
+            unet_key = (self.dtype_, round(float(r), 6), "unet")
+            if unet_key not in self._packers:
+                self._packers[unet_key] = Packer(w.unet, w.unet_scaling, self.dtype_, self.device_, r)
+            self._packers[key] = (self._packers[unet_key], Packer(vae_sd, w.vae_scaling, self.dtype_, self.device_, r))
+        return self._packers[key]
+
+    def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1) -> ForwardPlan:
+        r_eff = float(r) if stochastic else 1.0
+        key = (B, H, W, self.dtype_, stochastic, round(r_eff, 6), direction, ctx_batch)
+        if key not in self._plans:
+            self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
+                                           r=r_eff, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
+                                           flash=self.flash, packers=self._get_packers(r_eff, direction))
+        return self._plans[key]
+
+    def encode_prompt(self, prompt=None, prompt_tokens=None):
+        """tokenizer(prompt, max_length=77, padding="max_length", truncation=True) -> text_encoder(ids)[0]
+        (src/pix2pix_turbo.py:190-196).  Cached per prompt string."""
+        if self.text_encoder is None:
+            raise _capi.I2IError("no text encoder attached: pass caption_enc=[1|B,77,%d] or construct the model with "
+                                 "tokenizer= and text_encoder=" % self.weights.unet_arch.cross_attention_dim)
+        if prompt is not None:
+            key = prompt if isinstance(prompt, str) else tuple(prompt)
+            if key not in self._caption_cache:
+                ids = self.tokenizer(prompt, max_length=self.tokenizer.model_max_length, padding="max_length",
+                                     truncation=True, return_tensors="pt").input_ids
+                self._caption_cache[key] = self.text_encoder(ids.to(self.device_))[0].detach()
+            return self._caption_cache[key]
+        ids = prompt_tokens.reshape(-1, prompt_tokens.shape[-1])   # [B,1,77] from the training dataset (A.5)
+        return self.text_encoder(ids.to(self.device_))[0].detach()
+
+    def _execute(self, plan: ForwardPlan, x, caption_enc, eps, noise_map=None):
+        plan.x_in.copy_(x)
+        plan.ctx.copy_(caption_enc.reshape(plan.ctx.shape))
+        plan.eps.copy_(eps)
+        if noise_map is not None:
+            plan.noise.copy_(noise_map.expand_as(plan.noise))
+        if self.use_graph:
+            plan.replay()
+        else:
+            plan.run()
+        return plan.out.clone()
+
+
+class Pix2Pix_Turbo(TurboGeneratorBase):
+    def __init__(self, pretrained_name=None, pretrained_path=None, ckpt_folder="checkpoints", lora_rank_unet=8, lora_rank_vae=4,
+                 *, weights: Optional[GeneratorWeights] = None, base_dir=None, **kw):
+        if weights is None:
+            # local-file counterpart of src/pix2pix_turbo.py:47-130: base SD-Turbo snapshot + LoRA .pkl
+            import os
+            if base_dir is None:
+                raise ValueError("give weights=GeneratorWeights(...) or base_dir=<local sd-turbo snapshot> (no network here)")
+            names = {"edge_to_image": "edge_to_image_loras.pkl", "sketch_to_image_stochastic": "sketch_to_image_stochastic_lora.pkl"}
+            if pretrained_name in names:
+                pretrained_path = os.path.join(ckpt_folder, names[pretrained_name])
+            if pretrained_path is None:
+                raise ValueError("pretrained_name or pretrained_path required (random-init training models are out of scope)")
+            unet, vae = load_sd_turbo_base(base_dir)
+            weights = from_pix2pix_checkpoint(unet, vae, load_checkpoint_file(pretrained_path))
+        super().__init__(weights, **kw)
+        self.lora_rank_unet, self.lora_rank_vae = lora_rank_unet, lora_rank_vae
+
+    @torch.no_grad()
+    def forward(self, c_t, prompt=None, prompt_tokens=None, deterministic=True, r=1.0, noise_map=None,
+                *, caption_enc=None, eps=None):
+        if caption_enc is None:
+            # either the prompt or the prompt_tokens should be provided (src/pix2pix_turbo.py:188)
+            assert (prompt is None) != (prompt_tokens is None), "Either prompt or prompt_tokens should be provided"
+            caption_enc = self.encode_prompt(prompt, prompt_tokens)
+        B, _, H, W = c_t.shape
+        if not deterministic:
+            if noise_map is None:
+                raise ValueError("stochastic forward needs noise_map (src/pix2pix_turbo.py:210)")
+        elif self.weights.is_twin_conv:
+            raise ValueError("this checkpoint wraps conv_in in a TwinConv, which the reference can only run with "
+                             "deterministic=False (TwinConv.r is None otherwise, src/pix2pix_turbo.py:21-26)")
+        lat = self.weights.vae_arch.latent_channels
+        if eps is None:   # latent_dist.sample() draw, then the (numerically dead) scheduler draw: same order as the reference
+            eps = torch.randn(B, lat, H // 8, W // 8, device=self.device_, dtype=torch.float32)
+            torch.randn(B, lat, H // 8, W // 8, device=self.device_, dtype=torch.float32)
+        ctx_batch = caption_enc.shape[0] if caption_enc.dim() == 3 else 1
+        assert ctx_batch in (1, B)
+        plan = self.get_plan(B, H, W, stochastic=not deterministic, r=r, ctx_batch=ctx_batch)
+        out = self._execute(plan, c_t, caption_enc, eps, None if deterministic else noise_map)
+        return out.to(c_t.dtype) if c_t.dtype in (torch.float16, torch.bfloat16, torch.float32) else out
+
+    def save_model(self, outf):
+        """Same dict layout as the reference (src/pix2pix_turbo.py:221-229)."""
+        from .weights import GeneratorWeights  # noqa: F401
+        sd = {"unet_lora_target_modules": getattr(self, "target_modules_unet", None),
+              "vae_lora_target_modules": getattr(self, "target_modules_vae", None),
+              "rank_unet": self.lora_rank_unet, "rank_vae": self.lora_rank_vae,
+              "state_dict_unet": {k: v for k, v in self.weights.unet.items() if "lora" in k or "conv_in" in k},
+              "state_dict_vae": {k: v for k, v in self.weights.vae.items() if "lora" in k or "skip" in k}}
+        torch.save(sd, outf)

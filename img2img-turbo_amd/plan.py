@@ -1,0 +1,495 @@
+"""Forward planner: (weights, B, H, W, dtype, mode) -> a flat op program over static NHWC buffers.
+
+Not a walk over a diffusers module tree: the generator (src/pix2pix_turbo.py:197-203 /
+src/cyclegan_turbo.py:203-206 with the patched VAE forwards src/model.py:14-54) is flattened ahead of
+time into ~700 kernel launches on pre-allocated buffers, every norm / activation / residual / skip / concat /
+upsample folded into a neighbouring contraction, constants at t=999 folded at pack time.  The program is
+executed by one C call (``i2i_run``) or replayed as a hipGraph (``i2i_graph_launch``).
+
+Python only allocates tensors and writes op descriptors here; it never computes.
+"""
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import _capi as K
+from . import ops as O
+from .packer import Packer
+
+
+@dataclass
+class Act:
+    """An NHWC activation [n, h, w, c] living in ``t`` (channel stride 1, pixel stride = c)."""
+    t: torch.Tensor
+    n: int
+    h: int
+    w: int
+    c: int
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+
+class Pool:
+    """Size-keyed recycling of device buffers: the program is static and runs in order on one stream,
+    so a buffer can be handed out again as soon as the op list no longer reads it."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free_lists = {}
+        self.all = []
+        self.bytes = 0
+        self.no_reuse = False
+
+    def get(self, numel, dtype):
+        key = (numel, dtype)
+        fl = self.free_lists.get(key)
+        if fl:
+            return fl.pop()
+        t = torch.empty(numel, dtype=dtype, device=self.device)
+        self.all.append(t)
+        self.bytes += numel * t.element_size()
+        return t
+
+    def put(self, t):
+        if self.no_reuse:      # debugging aid: keep every intermediate intact after the run
+            return
+        self.free_lists.setdefault((t.numel(), t.dtype), []).append(t)
+
+
+def one_step_scheduler_constants(t=999, n=1000, beta_start=0.00085, beta_end=0.012):
+    """make_1step_sched (src/model.py:7-11): scaled_linear betas, fp32 cumprod; (sqrt(abar_t), sqrt(1-abar_t))."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)[t]
+    return float(ac ** 0.5), float((1 - ac) ** 0.5)
+
+
+class ForwardPlan:
+    """One planned forward for fixed (B, H, W, dtype, r, direction)."""
+
+    def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False):
+        assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
+        if (H // 8) % 8 or (W // 8) % 8:
+            raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
+                                      "upsample sizes (DESIGN.md row f3, not built yet)")
+        self.lib, self.w8s, self.B, self.H, self.W = lib, weights, B, H, W
+        self.dtype, self.device = dtype, device
+        self.dt = O.DT[dtype]
+        self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
+        self.fuse_gn, self.flash = fuse_gn, flash
+        self.ua, self.va = weights.unet_arch, weights.vae_arch
+        vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
+        if packers is None:
+            packers = (Packer(weights.unet, weights.unet_scaling, dtype, device, self.r),
+                       Packer(vae_sd, weights.vae_scaling, dtype, device, self.r))
+        self.pu, self.pv = packers
+        self.pool = Pool(device)
+        self.pool.no_reuse = debug
+        self.taps = {}          # label -> Act of that op's output (meaningful with debug=True)
+        self.prog = K.Program()
+        self.flops = 0
+        self.gn_partial = None
+        self.gn_ss = None
+        self._gn_part_elems = 0
+        self._gn_ss_elems = 0
+        self._pending_gn = []
+        lat = self.va.latent_channels
+        h8, w8 = H // 8, W // 8
+        self.out_dtype = out_dtype or dtype
+        # ---- static boundary buffers (graph-stable addresses) ----
+        self.x_in = torch.zeros(B, 3, H, W, dtype=torch.float32, device=device)
+        self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
+        self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
+        self.ctx_batch = ctx_batch
+        self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=dtype, device=device)
+        self.out = torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device)
+        self._build()
+        self._finish_gn_scratch()
+        self.prog.freeze()
+        self.graph = None
+
+    # ------------------------------------------------------------------ helpers
+    def _add(self, op, label):
+        self.prog.add(op[0], self.dt, op[1], label)
+
+    def new(self, n, h, w, c, dtype=None):
+        t = self.pool.get(n * h * w * c, dtype or self.dtype)
+        return Act(t, n, h, w, c)
+
+    def free(self, a):
+        self.pool.put(a.t if isinstance(a, Act) else a)
+
+    def _gn_scratch(self, nimg, ct, nparts, groups):
+        self._gn_part_elems = max(self._gn_part_elems, nimg * nparts * groups * 2)
+        self._gn_ss_elems = max(self._gn_ss_elems, nimg * ct * 2)
+
+    def _finish_gn_scratch(self):
+        self.gn_partial = torch.zeros(max(self._gn_part_elems, 1), dtype=torch.float32, device=self.device)
+        self.gn_ss = torch.zeros(max(self._gn_ss_elems, 1), dtype=torch.float32, device=self.device)
+        for p, which in self._pending_gn:   # patch pointers now that the scratch exists
+            if which == "stats":
+                p.partial, p.ss = self.gn_partial.data_ptr(), self.gn_ss.data_ptr()
+            elif which == "igemm":
+                p.gn_ss = self.gn_ss.data_ptr()
+            else:
+                p.ss = self.gn_ss.data_ptr()
+
+    def gn_stats(self, pk, norm_name, x: Act, groups, eps, x1: Optional[Act] = None, label=""):
+        gamma, beta = pk.norm(norm_name)
+        ct = x.c + (x1.c if x1 else 0)
+        nparts = int(min(256, max(1, (x.hw * ct) // 65536)))
+        self._gn_scratch(x.n, ct, nparts, groups)
+        op = O.gn_stats(x.t, gamma, beta, None, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=nparts,
+                        x1=x1.t if x1 else None, c0=x.c, c1=x1.c if x1 else 0, ld0=x.c, ld1=x1.c if x1 else 0)
+        self._pending_gn.append((op[1], "stats"))
+        self._add(op, label or norm_name)
+
+    def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, asym=False, x1: Optional[Act] = None, gn=False, act=0,
+             res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
+             label="") -> Act:
+        """One implicit-GEMM launch.  ``gn``: apply the pending GroupNorm scale/shift (+act) to the A operand."""
+        ks = ks or pw["ks"]
+        pad = (ks // 2 if not asym else 0) if pad is None else pad
+        hin, win = x.h, x.w
+        hu, wu = hin << ups, win << ups
+        if asym:           # F.pad(0,1,0,1) + stride-2 p0 (VAE Downsample2D)
+            ho, wo = (hu + 1 - ks) // stride + 1, (wu + 1 - ks) // stride + 1
+        else:
+            ho, wo = (hu + 2 * pad - ks) // stride + 1, (wu + 2 * pad - ks) // stride + 1
+        n_out = pw["n"] // 2 if geglu else pw["n"]
+        cp = cout_pad or ((n_out + 7) // 8 * 8)
+        if out is None:
+            out = self.new(x.n, ho, wo, cp, torch.float32 if out_f32 else None)
+        c1 = x1.c if x1 else 0
+        assert pw["w"].shape[1] == ks * ks * (x.c + c1), (label, pw["w"].shape, ks, x.c, c1)
+        x_in0, x_in1 = x, x1
+        if gn and not self.fuse_gn:
+            # unfused fallback: materialise act(GN(x)) first (single source only)
+            assert x1 is None
+            y = self.new(x.n, x.h, x.w, x.c)
+            op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act)
+            self._pending_gn.append((op[1], "apply"))
+            self._add(op, label + ".gn_apply")
+            x_in0 = y
+        op = O.conv(x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
+                    x1=x_in1.t if x_in1 else None, c0=x.c, c1=c1, lda0=x.c, lda1=c1, N=pw["n"],
+                    gn_ss=None, act=act if (gn and self.fuse_gn) else 0, bias=pw["b"], alpha=alpha,
+                    res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32)
+        if gn and self.fuse_gn:
+            self._pending_gn.append((op[1], "igemm"))
+            op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
+        self._add(op, label)
+        self.taps[label] = out
+        if gn and not self.fuse_gn:
+            self.free(x_in0)
+        self.flops += 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
+        return out
+
+    def linear(self, pw, x2d, rows, cin, *, out=None, res=None, geglu=0, label="", out_cols=None):
+        """Token-major linear: x2d is a flat tensor viewed as [rows][cin]."""
+        n_out = pw["n"] // 2 if geglu else pw["n"]
+        out_cols = out_cols or n_out
+        if out is None:
+            out = self.pool.get(rows * out_cols, self.dtype)
+        op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
+                    res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu)
+        self._add(op, label)
+        self.flops += 2 * rows * pw["n"] * cin
+        return out
+
+    # ------------------------------------------------------------------ blocks
+    def resnet(self, pk, prefix, x: Act, cout, groups, eps, x1: Optional[Act] = None, arch=None) -> Act:
+        split = x.c if x1 else None
+        self.gn_stats(pk, prefix + ".norm1", x, groups, eps, x1)
+        h = self.conv(pk.resnet_conv1(prefix, arch, split), x, x1=x1, gn=True, act=1, label=prefix + ".conv1")
+        self.gn_stats(pk, prefix + ".norm2", h, groups, eps)
+        if pk.has(prefix + ".conv_shortcut"):
+            sc = self.conv(pk.conv(prefix + ".conv_shortcut", split=split), x, x1=x1, label=prefix + ".conv_shortcut")
+            out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=sc, label=prefix + ".conv2")
+            self.free(sc)
+        else:
+            assert x1 is None
+            out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=x, label=prefix + ".conv2")
+        self.free(h)
+        return out
+
+    def vae_attention(self, pk, prefix, x: Act, groups, eps) -> Act:
+        """VAE mid attention (1 head of width C): GN -> q,k | v^T -> scores -> softmax -> p.v -> out + x.
+        Unfused (scores materialised): head dim 512 does not fit the d=64 flash kernel."""
+        B, T, C = x.n, x.hw, x.c
+        self.gn_stats(pk, prefix + ".group_norm", x, groups, eps)
+        xn = self.new(x.n, x.h, x.w, C)
+        op = O.gn_apply(x.t, xn.t, None, nimg=B, hw=T, c=C, act=0)
+        self._pending_gn.append((op[1], "apply"))
+        self._add(op, prefix + ".gn_apply")
+        qk = self.linear(pk.stacked_linear([prefix + ".to_q", prefix + ".to_k"]), xn.t, B * T, C, label=prefix + ".to_qk")
+        wv = pk.conv(prefix + ".to_v")
+        vt = self.pool.get(B * C * T, self.dtype)
+        self._add(O.bgemm(wv["w"], xn.t, vt, M=C, N=T, Kdim=C, lda=C, ldb=C, ldc=T, batch=B, heads=1, a_bs=(0, 0),
+                          b_bs=(T * C, 0), c_bs=(C * T, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T")
+        self.flops += 2 * B * T * C * C
+        self.free(xn)
+        s = self.pool.get(B * T * T, torch.float32)
+        self._add(O.bgemm(qk, qk[C:], s, M=T, N=T, Kdim=C, lda=2 * C, ldb=2 * C, ldc=T, batch=B, heads=1,
+                          a_bs=(T * 2 * C, 0), b_bs=(T * 2 * C, 0), c_bs=(T * T, 0), out_f32=1), prefix + ".qk^T")
+        p = self.pool.get(B * T * T, self.dtype)
+        self._add(O.softmax(s, p, rows=B * T, cols=T, lds=T, ldp=T, scale=1.0 / math.sqrt(C)), prefix + ".softmax")
+        self.pool.put(s)
+        self.pool.put(qk)
+        o = self.pool.get(B * T * C, self.dtype)
+        self._add(O.bgemm(p, vt, o, M=T, N=C, Kdim=T, lda=T, ldb=T, ldc=C, batch=B, heads=1, a_bs=(T * T, 0), b_bs=(C * T, 0),
+                          c_bs=(T * C, 0)), prefix + ".pv")
+        self.flops += 4 * B * T * T * C
+        self.pool.put(p)
+        self.pool.put(vt)
+        out = self.new(x.n, x.h, x.w, C)
+        self.linear(pk.conv(prefix + ".to_out.0"), o, B * T, C, out=out.t, res=x.t, label=prefix + ".to_out")
+        self.pool.put(o)
+        return out
+
+    def attention_block(self, pk, p, xn, x_res, B, T, C, heads, ctx=None, tk=None):
+        """attn1 (self) or attn2 (cross, ``ctx`` = text states).  Returns x_res + to_out(attn)."""
+        d = C // heads
+        scale = 1.0 / math.sqrt(d)
+        if ctx is None:
+            tk = T
+            qk = self.linear(pk.stacked_linear([p + ".to_q", p + ".to_k"]), xn, B * T, C, label=p + ".to_qk")
+            q, k, ldq, ldk, q_bs, k_bs = qk, qk[C:], 2 * C, 2 * C, T * 2 * C, T * 2 * C
+            kv_src, kv_cin, kv_bs = xn, C, T * C
+        else:
+            cd = self.ua.cross_attention_dim
+            q = self.linear(pk.conv(p + ".to_q"), xn, B * T, C, label=p + ".to_q")
+            k = self.linear(pk.conv(p + ".to_k"), ctx, self.ctx_batch * tk, cd, label=p + ".to_k")
+            ldq, ldk, q_bs = C, C, T * C
+            k_bs = tk * C if self.ctx_batch > 1 else 0
+            kv_src, kv_cin, kv_bs = ctx, cd, (tk * cd if self.ctx_batch > 1 else 0)
+            qk = None
+        epc = 4 if self.dtype == torch.float32 else 8
+        ldvt = (tk + epc - 1) // epc * epc
+        wv = pk.conv(p + ".to_v")
+        vb = B if (ctx is None or self.ctx_batch > 1) else 1
+        vt = self.pool.get(vb * C * ldvt, self.dtype)
+        self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
+                          a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T")
+        self.flops += 2 * vb * tk * C * kv_cin
+        o = self.pool.get(B * T * C, self.dtype)
+        if self.flash and d == 64:
+            self._add(O.attention(q, k, vt, o, batch=B, heads=heads, d=d, tq=T, tk=tk, ldq=ldq, ldk=ldk, ldvt=ldvt, ldo=C,
+                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(C * ldvt if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa")
+        else:
+            ldp = ldvt
+            s = self.pool.get(B * heads * T * tk, torch.float32)
+            self._add(O.bgemm(q, k, s, M=T, N=tk, Kdim=d, lda=ldq, ldb=ldk, ldc=tk, batch=B, heads=heads, a_bs=(q_bs, d),
+                              b_bs=(k_bs, d), c_bs=(heads * T * tk, T * tk), out_f32=1), p + ".qk^T")
+            pm = self.pool.get(B * heads * T * ldp, self.dtype)
+            self._add(O.softmax(s, pm, rows=B * heads * T, cols=tk, lds=tk, ldp=ldp, scale=scale), p + ".softmax")
+            self.pool.put(s)
+            # V^T pad columns are multiplied by exact zeros of P; keep them finite
+            self._add(O.bgemm(pm, vt, o, M=T, N=d, Kdim=ldp, lda=ldp, ldb=ldvt, ldc=C, batch=B, heads=heads,
+                              a_bs=(heads * T * ldp, T * ldp), b_bs=((C * ldvt if vb > 1 else 0), d * ldvt), c_bs=(T * C, d)), p + ".pv")
+            self.pool.put(pm)
+            self._zero_init.append(vt)
+        self.flops += 4 * B * heads * T * tk * d
+        if qk is not None:
+            self.pool.put(qk)
+        else:
+            self.pool.put(q)
+            self.pool.put(k)
+        self.pool.put(vt)
+        out = self.linear(pk.conv(p + ".to_out.0"), o, B * T, C, res=x_res, label=p + ".to_out")
+        self.pool.put(o)
+        return out
+
+    def transformer(self, pk, p, x: Act, heads, groups) -> Act:
+        """Transformer2DModel (1 BasicTransformerBlock, linear projections): GN(eps 1e-6) -> proj_in -> [attn1, attn2, GEGLU FF] -> proj_out + x."""
+        B, T, C = x.n, x.hw, x.c
+        rows = B * T
+        self.gn_stats(pk, p + ".norm", x, groups, 1e-6)
+        h = self.conv(pk.conv(p + ".proj_in"), x, ks=1, gn=True, act=0, label=p + ".proj_in").t   # tokens [rows][C]
+        t = p + ".transformer_blocks.0"
+
+        def ln(name, src):
+            g, b = pk.norm(name)
+            y = self.pool.get(rows * C, self.dtype)
+            self._add(O.layernorm(src, y, g, b, rows=rows, c=C, eps=1e-5), name)
+            return y
+
+        y = ln(t + ".norm1", h)
+        h2 = self.attention_block(pk, t + ".attn1", y, h, B, T, C, heads)
+        self.pool.put(y)
+        self.pool.put(h)
+        y = ln(t + ".norm2", h2)
+        h3 = self.attention_block(pk, t + ".attn2", y, h2, B, T, C, heads, ctx=self.ctx, tk=77)
+        self.pool.put(y)
+        self.pool.put(h2)
+        y = ln(t + ".norm3", h3)
+        ff = self.linear(pk.geglu_linear(t + ".ff.net.0.proj"), y, rows, C, geglu=1, label=t + ".ff.geglu")
+        self.pool.put(y)
+        h4 = self.linear(pk.conv(t + ".ff.net.2"), ff, rows, 4 * C, res=h3, label=t + ".ff.net.2")
+        self.pool.put(ff)
+        self.pool.put(h3)
+        out = self.new(x.n, x.h, x.w, C)
+        self.linear(pk.conv(p + ".proj_out"), h4, rows, C, out=out.t, res=x.t, label=p + ".proj_out")
+        self.pool.put(h4)
+        return out
+
+    # ------------------------------------------------------------------ the three networks
+    def _vae_encoder(self, x: Act):
+        pk, a = self.pv, self.va
+        g, eps = a.norm_num_groups, a.eps
+        boc = a.block_out_channels
+        h = self.conv(pk.conv("encoder.conv_in"), x, label="encoder.conv_in")
+        skips = []
+        for i, c in enumerate(boc):
+            skips.append(h)                                   # src/model.py:18-20 (kept alive for the decoder)
+            cur = h
+            for j in range(a.layers_per_block):
+                nxt = self.resnet(pk, f"encoder.down_blocks.{i}.resnets.{j}", cur, c, g, eps)
+                if cur is not h:
+                    self.free(cur)
+                cur = nxt
+            if i < len(boc) - 1:
+                nxt = self.conv(pk.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv"), cur, stride=2, asym=True,
+                                label=f"encoder.down_blocks.{i}.downsamplers.0.conv")
+                self.free(cur)
+                cur = nxt
+            h = cur
+        m = self.resnet(pk, "encoder.mid_block.resnets.0", h, boc[-1], g, eps)
+        self.free(h)                                          # down3 output is not a skip
+        m2 = self.vae_attention(pk, "encoder.mid_block.attentions.0", m, g, eps)
+        self.free(m)
+        m3 = self.resnet(pk, "encoder.mid_block.resnets.1", m2, boc[-1], g, eps)
+        self.free(m2)
+        self.gn_stats(pk, "encoder.conv_norm_out", m3, g, eps)
+        moments = self.conv(pk.encoder_out(), m3, gn=True, act=1, out_f32=1, label="encoder.conv_out+quant_conv")
+        self.free(m3)
+        return moments, skips
+
+    def _unet(self, u: Act) -> Act:
+        pk, a = self.pu, self.ua
+        g, eps = a.norm_num_groups, a.norm_eps
+        boc, heads = a.block_out_channels, a.num_heads
+        nb = len(boc)
+        conv_in = pk.twin_conv_in() if self.w8s.is_twin_conv else pk.conv("conv_in")
+        h = self.conv(conv_in, u, label="conv_in")
+        res = [h]
+        for i, c in enumerate(boc):
+            for j in range(a.layers_per_block):
+                h2 = self.resnet(pk, f"down_blocks.{i}.resnets.{j}", h, c, g, eps, arch=a)
+                if i < nb - 1:
+                    h3 = self.transformer(pk, f"down_blocks.{i}.attentions.{j}", h2, heads[i], g)
+                    self.free(h2)
+                    h2 = h3
+                h = h2
+                res.append(h)
+            if i < nb - 1:
+                h = self.conv(pk.conv(f"down_blocks.{i}.downsamplers.0.conv"), h, stride=2, label=f"down_blocks.{i}.downsamplers.0.conv")
+                res.append(h)
+        m = self.resnet(pk, "mid_block.resnets.0", h, boc[-1], g, eps, arch=a)
+        m2 = self.transformer(pk, "mid_block.attentions.0", m, heads[-1], g)
+        self.free(m)
+        h = self.resnet(pk, "mid_block.resnets.1", m2, boc[-1], g, eps, arch=a)
+        self.free(m2)
+        rheads = list(reversed(heads))
+        rboc = list(reversed(boc))
+        for i, c in enumerate(rboc):
+            for j in range(a.layers_per_block + 1):
+                skip = res.pop()
+                h2 = self.resnet(pk, f"up_blocks.{i}.resnets.{j}", h, c, g, eps, x1=skip, arch=a)   # cat([hidden, skip])
+                self.free(h)
+                self.free(skip)
+                if i > 0:
+                    h3 = self.transformer(pk, f"up_blocks.{i}.attentions.{j}", h2, rheads[i], g)
+                    self.free(h2)
+                    h2 = h3
+                h = h2
+            if i < nb - 1:
+                h2 = self.conv(pk.conv(f"up_blocks.{i}.upsamplers.0.conv"), h, ups=1, label=f"up_blocks.{i}.upsamplers.0.conv")
+                self.free(h)
+                h = h2
+        assert not res
+        self.gn_stats(pk, "conv_norm_out", h, g, eps)
+        e = self.conv(pk.conv("conv_out"), h, gn=True, act=1, out_f32=1, label="conv_out")     # eps-prediction kept fp32
+        self.free(h)
+        return e
+
+    def _vae_decoder(self, z: Act, skips: List[Act]) -> Act:
+        pk, a = self.pv, self.va
+        g, eps = a.norm_num_groups, a.eps
+        rboc = list(reversed(a.block_out_channels))
+        h = self.conv(pk.conv("decoder.conv_in"), z, label="decoder.conv_in")
+        m = self.resnet(pk, "decoder.mid_block.resnets.0", h, rboc[0], g, eps)
+        self.free(h)
+        m2 = self.vae_attention(pk, "decoder.mid_block.attentions.0", m, g, eps)
+        self.free(m)
+        h = self.resnet(pk, "decoder.mid_block.resnets.1", m2, rboc[0], g, eps)
+        self.free(m2)
+        for i, c in enumerate(rboc):
+            sk = skips[::-1][i]
+            # sample = sample + skip_conv_i(skip * gamma)   (src/model.py:41-43), in place
+            self.conv(pk.conv(f"decoder.skip_conv_{i + 1}"), sk, ks=1, alpha=self.r, res=h, out=h, label=f"decoder.skip_conv_{i + 1}")
+            self.free(sk)
+            for j in range(a.layers_per_block + 1):
+                h2 = self.resnet(pk, f"decoder.up_blocks.{i}.resnets.{j}", h, c, g, eps)
+                self.free(h)
+                h = h2
+            if i < len(rboc) - 1:
+                h2 = self.conv(pk.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv"), h, ups=1, label=f"decoder.up_blocks.{i}.upsamplers.0.conv")
+                self.free(h)
+                h = h2
+        self.gn_stats(pk, "decoder.conv_norm_out", h, g, eps)
+        y = self.conv(pk.conv("decoder.conv_out"), h, gn=True, act=1, label="decoder.conv_out")
+        self.free(h)
+        return y
+
+    def _build(self):
+        B, H, W = self.B, self.H, self.W
+        lat = self.va.latent_channels
+        h8, w8 = H // 8, W // 8
+        self._zero_init = []
+        x = self.new(B, H, W, 8)
+        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8), "input.nchw_to_nhwc")
+        moments, skips = self._vae_encoder(x)
+        # x (= conv_in input) is not a skip; skips[0] is conv_in's output
+        self.free(x)
+        u = self.new(B, h8, w8, 8)
+        self.u32 = torch.zeros(B * h8 * w8 * lat, dtype=torch.float32, device=self.device)
+        sf = self.va.scaling_factor
+        self._add(O.posterior(moments.t, self.eps, u.t, n=B, hw=h8 * w8, lat=lat, ldm=moments.c, ldu=8, sf=sf, r=self.r,
+                              noise=self.noise, noise_n=B, u_f32=self.u32, moments_f32=1), "posterior_sample")
+        self.free(moments)
+        e = self._unet(u)
+        self.free(u)
+        sa, s1 = one_step_scheduler_constants(self.ua.timestep)
+        wpq, bpq = self.pv.small_f32("post_quant_conv")
+        z = self.new(B, h8, w8, 8)
+        self._add(O.ddpm_postquant(self.u32, e.t, z.t, wpq, bpq, n=B, hw=h8 * w8, lat=lat, ldu=lat, lde=e.c, ldy=8,
+                                   sqrt_abar=sa, sqrt_1m_abar=s1, sf=sf, u_f32=1, e_f32=1), "ddpm_step+post_quant")
+        self.free(e)
+        y = self._vae_decoder(z, skips)
+        self.free(z)
+        self._add(O.nhwc_to_nchw(y.t, self.out, n=B, c=3, h=H, w=W, ldx=y.c, clamp=1), "output.nhwc_to_nchw")
+        for t in self._zero_init:
+            t.zero_()
+
+    # ------------------------------------------------------------------ execution
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream if torch.device(self.device).type == "cuda" else 0
+
+    def run(self):
+        self.lib.run(self.prog, self.stream())
+
+    def capture(self):
+        if self.graph is None:
+            self.graph = self.lib.graph_create(self.prog)
+        return self.graph
+
+    def replay(self):
+        self.lib.graph_launch(self.capture(), self.stream())
+
+    def run_timed(self):
+        return self.lib.run_timed(self.prog, self.stream())
