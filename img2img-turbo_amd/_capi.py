@@ -103,6 +103,30 @@ class I2IError(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Streams, events and graphs are only
+    meaningful inside ONE HIP runtime instance, so make sure torch's copy is the one already mapped when the
+    kernel library's DT_NEEDED entry is resolved (the loader then binds to it by SONAME)."""
+    import torch
+    hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
+def _assert_single_hip_runtime():
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise I2IError("two HIP runtimes are mapped in this process (%s): import torch before loading the kernel "
+                       "library so both share one runtime" % sorted(paths))
+
+
 class Library:
     """One loaded libi2i_turbo.so.  ``path`` defaults to the in-tree product build."""
 
@@ -113,7 +137,9 @@ class Library:
                 "HIP kernel library not found at %s -- build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
         self.path = path
+        _preload_torch_hip_runtime()
         self.lib = C.CDLL(path)
+        _assert_single_hip_runtime()
         missing = [s for s in EXPORTS if not hasattr(self.lib, s)]
         if missing:
             raise I2IError("library %s lacks ABI symbols: %s" % (path, missing))

@@ -19,6 +19,11 @@
 #include "i2i_dev.h"
 #include "launch.h"
 
+namespace i2i {
+bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype);   // conv3x3.hip
+int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s);
+}  // namespace i2i
+
 namespace {
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -287,6 +292,10 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     if (p.geglu && (p.N % 32 || p.out_f32 || p.bias_mode == 2)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad geglu config");
     if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b) & 15) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+    // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
+    if (p.tile == 10 && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile 10 (halo conv) not applicable");
+    if ((p.tile == 0 || p.tile == 10) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     switch (dtype) {
         case I2I_F32: return launch_t<float>(p, s);
         case I2I_BF16: return launch_t<__bf16>(p, s);

@@ -91,6 +91,7 @@ class ForwardPlan:
         self.pool.no_reuse = debug
         self.taps = {}          # label -> Act of that op's output (meaningful with debug=True)
         self.prog = K.Program()
+        self.op_flops = []      # algorithmic FLOPs per op (2*MAC), parallel to prog.ops
         self.flops = 0
         self.gn_partial = None
         self.gn_ss = None
@@ -113,8 +114,9 @@ class ForwardPlan:
         self.graph = None
 
     # ------------------------------------------------------------------ helpers
-    def _add(self, op, label):
+    def _add(self, op, label, flops=0):
         self.prog.add(op[0], self.dt, op[1], label)
+        self.op_flops.append(flops)
 
     def new(self, n, h, w, c, dtype=None):
         t = self.pool.get(n * h * w * c, dtype or self.dtype)
@@ -167,9 +169,9 @@ class ForwardPlan:
         c1 = x1.c if x1 else 0
         assert pw["w"].shape[1] == ks * ks * (x.c + c1), (label, pw["w"].shape, ks, x.c, c1)
         x_in0, x_in1 = x, x1
-        if gn and not self.fuse_gn:
+        fused = self.fuse_gn or x1 is not None     # the two-source (concat) case always applies GN in the gather
+        if gn and not fused:
             # unfused fallback: materialise act(GN(x)) first (single source only)
-            assert x1 is None
             y = self.new(x.n, x.h, x.w, x.c)
             op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act)
             self._pending_gn.append((op[1], "apply"))
@@ -177,16 +179,17 @@ class ForwardPlan:
             x_in0 = y
         op = O.conv(x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
                     x1=x_in1.t if x_in1 else None, c0=x.c, c1=c1, lda0=x.c, lda1=c1, N=pw["n"],
-                    gn_ss=None, act=act if (gn and self.fuse_gn) else 0, bias=pw["b"], alpha=alpha,
+                    gn_ss=None, act=act if (gn and fused) else 0, bias=pw["b"], alpha=alpha,
                     res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32)
-        if gn and self.fuse_gn:
+        if gn and fused:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
-        self._add(op, label)
+        fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
+        self._add(op, label, fl)
         self.taps[label] = out
-        if gn and not self.fuse_gn:
+        if gn and not fused:
             self.free(x_in0)
-        self.flops += 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
+        self.flops += fl
         return out
 
     def linear(self, pw, x2d, rows, cin, *, out=None, res=None, geglu=0, label="", out_cols=None):
@@ -197,7 +200,7 @@ class ForwardPlan:
             out = self.pool.get(rows * out_cols, self.dtype)
         op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
                     res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu)
-        self._add(op, label)
+        self._add(op, label, 2 * rows * pw["n"] * cin)
         self.flops += 2 * rows * pw["n"] * cin
         return out
 

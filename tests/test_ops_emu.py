@@ -100,3 +100,21 @@ def test_attention(emu_lib, dtype):
 def test_boundary_and_latent_ops(emu_lib, dtype):
     oc.check_boundary(emu_lib, "cpu", dtype)
     oc.check_latent_ops(emu_lib, "cpu", dtype)
+
+
+# ---- halo-tiled 3x3 kernel (conv3x3.hip): tile 10 forces it, so a silent fall-back to the generic kernel fails ----
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_halo_conv_basic(emu_lib, dtype):
+    oc.check_conv(emu_lib, "cpu", dtype, n=2, cin=64, cout=48, h=16, w=32, tile=10)
+
+
+def test_halo_conv_gn_residual_partial_tiles(emu_lib):
+    # plane 12x20: partial tiles in both directions; two slabs (f32: 4 slabs) exercise the halo prefetch ring
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=128, h=12, w=20, gn=True, act=1, groups=8, res=True, tile=10)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=128, cout=32, h=12, w=20, gn=True, act=1, groups=8, res=True, tile=10)
+
+
+def test_halo_conv_upsample_concat_smallN(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=32, cout=64, h=8, w=8, ups=1, tile=10)              # Upsample2D gather
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=64, h=8, w=16, gn=True, act=1, groups=8, tile=10)  # concat
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=64, cout=3, h=8, w=16, gn=True, act=1, groups=8, tile=10)   # conv_out (BN=16)

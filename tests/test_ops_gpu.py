@@ -62,3 +62,13 @@ def test_attention(gpu_lib, dtype):
 def test_boundary_and_latent_ops(gpu_lib, dtype):
     oc.check_boundary(gpu_lib, "cuda", dtype, n=2, h=64, w=48)
     oc.check_latent_ops(gpu_lib, "cuda", dtype, n=3, h=16, w=16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_halo_conv(gpu_lib, dtype):
+    """conv3x3.hip forced (tile 10) at tile-filling and ragged shapes, every gather/epilogue mode."""
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=64, w=64, gn=True, act=1, groups=32, res=True, tile=10)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=256, cout=192, h=20, w=36, gn=True, act=1, groups=32, tile=10)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=64, cout=64, h=16, w=16, ups=1, tile=10)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cin2=64, cout=128, h=16, w=32, gn=True, act=1, groups=32, tile=10)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=3, h=32, w=32, gn=True, act=1, groups=32, tile=10)

@@ -1,0 +1,129 @@
+"""Known-answer tests that pin the CPU oracle (the reference ships no tests or golden vectors: PARITY UNPINNED;
+see oracle/__init__.py).  Analytic constants from SURVEY.md 8(c) / Appendix A, exact parameter counts of the
+published SD-2.1 / SD-Turbo networks, and algebraic identities of the reference forward."""
+import math
+
+import pytest
+import torch
+
+from oracle import SD_TURBO_UNET, SD_TURBO_VAE, TINY_UNET, TINY_VAE
+from oracle.nn import Weights, conv2d, linear, timestep_embedding
+from oracle.pipeline import cyclegan_forward, pix2pix_forward
+from oracle.sched import alphas_cumprod, ddpm_step, one_step_constants
+from oracle.synth import (count_params, cyclegan_unet_target_split, make_cyclegan_weights, make_inputs,
+                          make_pix2pix_weights, peft_match, unet_layers, vae_layers, PIX2PIX_UNET_TARGETS, PIX2PIX_VAE_TARGETS)
+
+
+def test_scheduler_constants():
+    ac = alphas_cumprod()
+    assert abs(float(ac[999]) - 0.0046600951) < 1e-9
+    sa, s1 = one_step_constants(999)
+    assert abs(sa - 0.06826489) < 1e-7 and abs(s1 - 0.99766723) < 1e-7
+    assert abs(1 / sa - 14.648819) < 1e-4
+    x, e = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    got = ddpm_step(e, x)
+    assert torch.allclose(got, 14.648819 * x - 14.614647 * e, atol=2e-4)
+    n = torch.randn(2, 4, 8, 8)
+    assert (ddpm_step(e, x, variance_noise=n) - got).abs().max() < 1e-8      # 1e-10-scaled noise is numerically dead
+
+
+def test_timestep_embedding_head():
+    e = timestep_embedding(999, 320)[0]
+    assert torch.allclose(e[:3], torch.tensor([0.9996, 0.8027, -0.2781]), atol=2e-4)       # cos(999 f_i)
+    assert torch.allclose(e[160:163], torch.tensor([-0.0265, 0.5964, -0.9606]), atol=2e-4)  # sin(999 f_i)
+
+
+def test_parameter_counts_match_published_networks():
+    assert count_params(unet_layers(SD_TURBO_UNET)) == 865_910_724
+    assert count_params(vae_layers(SD_TURBO_VAE)) == 83_653_863 + 491_520    # + the four bias-free skip convs
+
+
+def test_lora_target_counts():
+    ul, vl = unet_layers(SD_TURBO_UNET), vae_layers(SD_TURBO_VAE)
+    unet_hit = [n for n, k, _ in ul if k != "norm" and peft_match(n, PIX2PIX_UNET_TARGETS)]
+    vae_hit = [n for n, k, _ in vl if k != "norm" and peft_match(n, PIX2PIX_VAE_TARGETS)]
+    assert len(unet_hit) == 257 and "conv_in" not in unet_hit and not any("time_emb" in n for n in unet_hit)
+    assert len(vae_hit) == 74 and "quant_conv" not in vae_hit and "post_quant_conv" not in vae_hit
+    enc, dec, oth = cyclegan_unet_target_split(SD_TURBO_UNET)
+    assert len(enc) + len(dec) + len(oth) == 258 and "conv_in" in enc and "conv_out" in oth
+
+
+def test_lora_merged_equals_unmerged():
+    g = torch.Generator().manual_seed(0)
+    sd = {"c.base_layer.weight": torch.randn(6, 5, 3, 3, generator=g), "c.base_layer.bias": torch.randn(6, generator=g),
+          "c.lora_A.ad.weight": torch.randn(2, 5, 3, 3, generator=g), "c.lora_B.ad.weight": torch.randn(6, 2, 1, 1, generator=g),
+          "l.base_layer.weight": torch.randn(7, 5, generator=g),
+          "l.lora_A.ad.weight": torch.randn(3, 5, generator=g), "l.lora_B.ad.weight": torch.randn(7, 3, generator=g)}
+    W = Weights(sd, {"ad": 2.0})
+    x = torch.randn(2, 5, 9, 9, generator=g)
+    wm, bm = W.merged("c")
+    for stride, pad in ((1, 1), (2, 0)):
+        assert torch.allclose(conv2d(W, "c", x, stride=stride, padding=pad), torch.nn.functional.conv2d(x, wm, bm, stride=stride, padding=pad), atol=1e-5)
+    t = torch.randn(4, 5, generator=g)
+    wl, _ = W.merged("l")
+    assert torch.allclose(linear(W, "l", t), t @ wl.t(), atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=3)
+    x, cap, eps, nm = make_inputs("canny", 2, 64, 64, TINY_UNET.cross_attention_dim)
+    return mw, x, cap, eps, nm
+
+
+def test_gamma1_stochastic_equals_deterministic(tiny):
+    mw, x, cap, eps, nm = tiny
+    a = pix2pix_forward(mw, x, cap, eps)
+    b = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=1.0, noise_map=nm)
+    assert torch.equal(a, b)
+
+
+def test_zero_skip_convs_make_skips_inert(tiny):
+    mw, x, cap, eps, _ = tiny
+    import copy
+    m2 = copy.copy(mw)
+    m2.vae = dict(mw.vae)
+    for k in list(m2.vae):
+        if "skip_conv" in k:
+            m2.vae[k] = torch.zeros_like(m2.vae[k])
+    out, inter = pix2pix_forward(m2, x, cap, eps, return_intermediates=True)
+    from oracle.vae import decoder_forward
+    no_skip = decoder_forward(m2.W_vae(), m2.vae_arch, inter["x0"] / 0.18215, None).clamp(-1, 1)
+    assert torch.allclose(out, no_skip, atol=1e-6)
+
+
+def test_twinconv_folds_to_one_conv():
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=4, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    r = 0.4
+    ref = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=r, noise_map=nm)
+    import copy
+    m2 = copy.copy(mw)
+    m2.unet = dict(mw.unet)
+    w1, b1 = m2.unet.pop("conv_in.conv_in_pretrained.weight"), m2.unet.pop("conv_in.conv_in_pretrained.bias")
+    w2, b2 = m2.unet.pop("conv_in.conv_in_curr.weight"), m2.unet.pop("conv_in.conv_in_curr.bias")
+    m2.unet["conv_in.weight"], m2.unet["conv_in.bias"] = w1 * (1 - r) + w2 * r, b1 * (1 - r) + b2 * r
+    got = pix2pix_forward(m2, x, cap, eps, deterministic=False, r=r, noise_map=nm)
+    assert (got - ref).abs().max() < 5e-4
+    with pytest.raises(ValueError):
+        pix2pix_forward(mw, x, cap, eps)     # TwinConv with r=None: the reference crashes, the oracle raises
+
+
+def test_cyclegan_directions_use_different_vaes():
+    mw = make_cyclegan_weights(TINY_UNET, TINY_VAE, rank_unet=16)
+    x, cap, eps, _ = make_inputs("photo", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    a, b = cyclegan_forward(mw, x, cap, eps, "a2b"), cyclegan_forward(mw, x, cap, eps, "b2a")
+    assert (a - b).abs().max() > 1e-2
+    assert a.abs().max() <= 1.0
+
+
+def test_golden_fixture_matches(tiny):
+    """tests/golden/tiny_pix2pix.pt (made by tests/golden/make_golden.py): the oracle must keep reproducing it."""
+    import os
+    p = os.path.join(os.path.dirname(__file__), "golden", "tiny_pix2pix.pt")
+    g = torch.load(p)
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=g["seed"])
+    x, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim, seed=g["input_seed"])
+    out = pix2pix_forward(mw, x, cap, eps)
+    assert (out[0, :, ::4, ::4] - g["out_sub"]).abs().max() < 1e-4
+    assert abs(out.double().sum().item() - g["sum"]) < 1e-2
