@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 F_ALG = {512: 4.477e12, 1024: 20.22e12}   # algorithmic FLOP / image
 PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+CPU_BASELINE_THREADS = 16
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
@@ -74,7 +75,9 @@ def cpu_baseline(weights, size, seed):
     from oracle.pipeline import ModelWeights, pix2pix_forward
     mw = ModelWeights(weights.unet, weights.vae, weights.unet_arch, weights.vae_arch, weights.unet_scaling, weights.vae_scaling)
     x, cap, eps = synth_inputs(1, size, weights.unet_arch.cross_attention_dim, weights.vae_arch.latent_channels, "cpu", seed)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # oneDNN/OpenMP oversubscribe badly past a few dozen threads on these shapes (256 threads: 488 s for one
+    # forward on the 256-core GPU box, 8 threads: 32 s): cap the pool and report the cap as `cores`
+    torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
     t0 = time.time()
     out = pix2pix_forward(mw, x, cap, eps)
     dt = time.time() - t0

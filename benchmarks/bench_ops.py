@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--out", default="gpurun_out/bench_ops.json")
+    ap.add_argument("--only", default="", help="substring filter on shape names")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = 157.3 if a.dtype == "f32" else 2500.0
@@ -52,6 +53,8 @@ def main():
     dev = "cuda"
     res = []
     for name, cin, cout, H, W, ks, stride, ups, gn in SHAPES:
+        if a.only and not any(t in name for t in a.only.split(',')):
+            continue
         B = a.batch
         x = torch.randn(B, H, W, cin, device=dev).to(dt)
         w = (torch.randn(cout, ks * ks * cin, device=dev) / math.sqrt(ks * ks * cin)).to(dt)
@@ -66,7 +69,11 @@ def main():
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
                                       N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile), dt))
             prog.freeze()
-            ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]
+            try:
+                ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]
+            except Exception as e:      # forced tile id not applicable to this shape
+                print("%-32s tile %d  n/a (%s)" % (name, tile, str(e)[:60]), flush=True)
+                continue
             t = sorted(ms)[len(ms) // 2]
             fl = 2.0 * B * ho * wo * cout * ks * ks * cin
             tf = fl / (t * 1e-3) / 1e12

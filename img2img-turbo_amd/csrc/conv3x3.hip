@@ -1,35 +1,54 @@
-// Halo-tiled 3x3 stride-1 pad-1 implicit-GEMM convolution for gfx950 -- the kernel that carries ~85 % of
+// Halo-tiled 3x3 stride-1 pad-1 implicit-GEMM convolution for gfx950 -- the kernel that carries ~87 % of
 // the forward's FLOPs (every resnet conv and upsampler conv of the VAE and UNet; F.conv2d in
-// diffusers ResnetBlock2D / Upsample2D).
+// diffusers ResnetBlock2D / Upsample2D, with the preceding F.group_norm + F.silu, F.interpolate(nearest 2x)
+// and torch.cat folded into the operand staging, bias / residual into the epilogue).
 //
-// Versus the generic im2col gather of igemm.hip (which restages each input element once per tap), a
-// workgroup here owns a TH x TW = 8 x 16 pixel output tile of ONE image and stages, per 64-channel slab
-// (32 for f32), the (TH+2) x (TW+2) input halo ONCE: global_load_dwordx4 -> GroupNorm affine + SiLU in
-// registers -> ds_write_b128 into an XOR-swizzled LDS image.  The nine taps then read their A fragments
-// from that single image at shifted pixel rows, so the prologue VALU work, the A-side global traffic and the
-// LDS writes all drop ~6.4x (9 taps / 1.4 halo overhead); only the [BN][64] weight slab changes per tap.
-// The halo of the next slab is fetched one chunk per tap-step behind the MFMAs (register-staged, written
-// at the end of the step into the other halo buffer); weights are double-buffered per step; one barrier
-// per step.  Nearest-2x upsampling is an index map while staging the halo (Upsample2D never materialises).
-// Each output m-fragment is one 16-pixel tile row, so the MFMA A operand of tap (dy,dx) is the halo row
-// segment starting at (ty+dy, dx): 16 consecutive 128-byte LDS rows.
+// Workgroup = TH x 16 output pixels of ONE image x BN output channels; WM x WN waves, each owning
+// TH/WM tile rows x BN/WN channels as 16x16 fp32 MFMA fragments.  K loop = (channel slab of 64 halves /
+// 32 floats) x (9 taps):
+//   * A operand (pixels): the (TH+2) x 18 input halo of the slab is staged ONCE per slab
+//     (global_load_dwordx4 -> GroupNorm affine + SiLU in registers -> ds_write_b128) and the nine taps
+//     read their fragments from that one LDS image at shifted rows; an m-fragment is one 16-pixel tile
+//     row, so tap (dy,dx) reads 16 consecutive 128-byte rows starting at (ty+dy)*18 + dx.  The XOR
+//     swizzle lds_chunk_off2 keeps those reads conflict-free for every start row.
+//   * B operand (weights [N][9*Cin], LoRA merged): streamed by LDS-DMA (global_load_lds_dwordx4) into a
+//     double buffer, one [BN][64] slab per tap, issued one tap ahead; the per-lane SOURCE address carries
+//     the swizzle, the LDS destination is lane-linear.  No VGPRs, no ds_write, no VALU.
+//   * one raw s_barrier per tap (plus one per slab for the halo hand-over); vmcnt is only drained where
+//     the DMA result is needed.  LDS = halo (single buffer: the next slab's halo waits in registers) +
+//     2 weight buffers = 72.5 KiB for the 16x16x128 tile, so two workgroups share a CU and cover each
+//     other's prologue / slab hand-over / epilogue.
+//   * MFMA operands are issued swapped (A = weights, B = pixels) so an accumulator lane holds 4
+//     CONSECUTIVE channels of one pixel: bias / residual / store move as 8-byte (16-byte fp32) vectors.
+// Nearest-2x upsampling is an index map while staging the halo (Upsample2D never materialises).
 #include "i2i_dev.h"
 #include "launch.h"
 
 namespace {
 
-constexpr int TH = 8, TW = 16, HW2 = TW + 2, HALO = (TH + 2) * (TW + 2);   // 180 halo pixels
+constexpr int TW = 16, HW2 = TW + 2;
+template <int V> struct ic { static constexpr int value = V; };   // compile-time int passed through generic lambdas
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {   // f(ic<0>{}) ... f(ic<N-1>{})
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(ic<N - 1>{});
+    }
+}
 
-template <typename T, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const i2i_igemm_params p) {
-    constexpr int NT = 256;
+// PD = pixel-fragment prefetch distance in row groups (2 or 3); MINW = min waves per SIMD for the register allocator
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i2i_igemm_params p) {
+    constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int CK = 8 * EPC;                      // channels per slab: 64 (16-bit) / 32 (f32)
-    static_assert(WM * WN == 4 && TH % WM == 0 && BN % (16 * WN) == 0, "");
-    constexpr int WTN = BN / WN, FN = WTN / 16;      // wave: 4 tile rows x WTN channels
-    constexpr int FM = (TH / WM);                    // m-fragments per wave = tile rows per wave
-    constexpr int BPT = (BN * 8 + NT - 1) / NT;
-    constexpr int HPT = (HALO * 8 + NT - 1) / NT;    // halo chunks per thread per slab (6)
+    constexpr int HALO = (TH + 2) * HW2;
+    static_assert(TH % WM == 0 && BN % (16 * WN) == 0, "");
+    constexpr int FM = TH / WM;                      // m-fragments per wave = tile rows per wave
+    constexpr int WTN = BN / WN, FN = WTN / 16;
+    constexpr int HPT = (HALO * 8 + NT - 1) / NT;    // halo chunks per thread per slab
+    constexpr int NPIECE = BN / 8;                   // 1-KiB LDS-DMA pieces per weight slab (8 rows each)
+    constexpr int BPW = (NPIECE + NW - 1) / NW;      // pieces per wave
+    constexpr int MPC = (EPC == 4) ? 4 : 1;          // MFMA instructions per chunk pair (f32: 4 x 16x16x4)
     typedef typename Elem<T>::chunk_t chunk_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -37,9 +56,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const i2i_igemm_param
     const int lr = lane & 15, lq = lane >> 4;
     const int kc = tid & 7;
 
+    // ---- XCD-aware tile id: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles so
+    // neighbouring tiles (shared halo rows, same weights) meet in the same L2 (bijective for any grid).
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
     const int ntn = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
     const int tn = bid % ntn; bid /= ntn;
     const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * TH;
@@ -53,74 +79,92 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const i2i_igemm_param
     const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
     const bool has_gn = p.gn_ss != nullptr;
 
-    char* Hs = i2i_smem;                                   // [2][HALO] rows of 128 B
-    char* Bs = i2i_smem + 2 * HALO * 128;                  // [2][BN]   rows of 128 B
+    char* Hs = i2i_smem;                             // [HALO] rows of 128 B (one slab)
+    char* Bs = i2i_smem + HALO * 128;                // [3][BN] rows of 128 B (step s lives in buffer tap % 3)
+    char* Ss = Bs + 3 * BN * 128;                    // [CK][2] fp32 GroupNorm (scale, shift) of the slab in flight
 
-    // this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3 (kc is constant = tid&7)
-    int h_off[HPT];       // element offset of the source pixel (without channel), -1 if outside the image
+    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
+    // One 32-bit pixel index per chunk (inside image `img`; ~0 = zero padding); the byte offset
+    // pixel * ld + kc*16 is formed at the load against a wave-uniform base (SGPR base + 32-bit VGPR offset).
+    unsigned hpix[HPT];
 #pragma unroll
     for (int j = 0; j < HPT; ++j) {
         const int hp = (tid >> 3) + j * (NT / 8);
-        int off = -1;
+        unsigned pix = ~0u;
         if (hp < HALO) {
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
             if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up)
-                off = (img * p.hin + (iy >> p.ups)) * p.win + (ix >> p.ups);
+                pix = (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
         }
-        h_off[j] = off;
+        hpix[j] = pix;
     }
+    const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
+    const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
 
-    float ssr[2 * EPC];
-    chunk_t rb[BPT];
-    chunk_t rh = zero_chunk<T>();   // the one halo chunk in flight during a step
-
-    const int nslab = cin / CK;
-    const int nstep = nslab * 9;
-
-    auto load_ss = [&](int slab) {
-        const f32x4* s = (const f32x4*)(p.gn_ss + ((int64_t)img * cin + slab * CK + kc * EPC) * 2);
+    // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3),
+    // physical chunk lane&7, i.e. source chunk (lane&7) ^ swz(row).  Rows past N are clamped (their
+    // accumulator columns are never stored).
+    unsigned b_voff[BPW];     // per-lane BYTE offset inside the weight matrix (N*ldb*sizeof(T) < 2^32)
 #pragma unroll
-        for (int q = 0; q < EPC / 2; ++q) {
-            const f32x4 v = s[q];
-            ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
+    for (int q = 0; q < BPW; ++q) {
+        const int pc = wave + q * NW;
+        const int row = pc * 8 + (lane >> 3);
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        b_voff[q] = (unsigned)(n * p.ldb + (((lane & 7) ^ lds_swz2(row)) * EPC)) * (unsigned)sizeof(T);
+    }
+    auto b_dma = [&](int slab, int tap, int buf) __attribute__((always_inline)) {
+        const char* src = (const char*)(bw + (tap * cin + slab * CK));      // wave-uniform part of the address
+#pragma unroll
+        for (int q = 0; q < BPW; ++q) {
+            const int pc = wave + q * NW;
+            if (NPIECE % NW == 0 || pc < NPIECE) glds16(src + b_voff[q], Bs + buf * BN * 128 + pc * 1024);
         }
     };
-    auto halo_load = [&](int slab, int j) -> chunk_t {
-        const int ci = slab * CK + kc * EPC;
-        const int off = h_off[j];
-        if (off < 0) return zero_chunk<T>();
-        if (ci < p.c0) return *(const chunk_t*)(a0 + (int64_t)off * p.lda0 + ci);
-        return *(const chunk_t*)(a1 + (int64_t)off * p.lda1 + (ci - p.c0));
+
+    chunk_t rh[HPT];
+
+    // GroupNorm (scale, shift) of the slab's CK channels: CK*8 bytes by LDS-DMA into Ss (one partial piece)
+    auto ss_dma = [&](int slab) __attribute__((always_inline)) {
+        if (wave == 0 && lane < CK / 2)
+            glds16(p.gn_ss + ((int64_t)img * cin + slab * CK) * 2 + lane * 4, Ss);
     };
-    auto halo_store = [&](int buf, int j, chunk_t c) {
-        const int hp = (tid >> 3) + j * (NT / 8);
-        if (hp >= HALO) return;
-        if (has_gn && h_off[j] >= 0) {       // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
+    auto halo_load = [&](int slab, int j) __attribute__((always_inline)) {
+        const int ci = slab * CK;                                       // wave-uniform source select
+        const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
+        const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
+        if (hpix[j] == ~0u) rh[j] = zero_chunk<T>();
+        else rh[j] = *(const chunk_t*)(base + (hpix[j] * ldb + (unsigned)kc * 16u));
+    };
+    auto halo_store_all = [&]() __attribute__((always_inline)) {
+        float ssr[2 * EPC];
+        if (has_gn) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float v = to_f32<T>(c[e]) * ssr[2 * e] + ssr[2 * e + 1];
-                if (p.act == 1) v = silu_f(v);
-                c[e] = from_f32<T>(v);
+            for (int q = 0; q < EPC / 2; ++q) {
+                const f32x4 v = *(const f32x4*)(Ss + kc * EPC * 8 + q * 16);
+                ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
             }
         }
-        *(chunk_t*)(Hs + buf * HALO * 128 + lds_chunk_off(hp, kc)) = c;
-    };
-    auto b_load = [&](int step) {
-        const int slab = step / 9, tap = step - slab * 9;
-        const int k = tap * cin + slab * CK + kc * EPC;
+        const bool silu = p.act == 1;
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int v = tid + j * NT;
-            const int n = n0 + (v >> 3);
-            rb[j] = (v < BN * 8 && n < p.N) ? *(const chunk_t*)(bw + (int64_t)n * p.ldb + k) : zero_chunk<T>();
-        }
-    };
-    auto b_store = [&](int buf) {
+        for (int j = 0; j < HPT; ++j) {
+            const int hp = (tid >> 3) + j * (NT / 8);
+            if (hp < HALO) {
+                chunk_t c = rh[j];
+                if (has_gn && hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
+                    float v[EPC];
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int v = tid + j * NT;
-            if (v < BN * 8) *(chunk_t*)(Bs + buf * BN * 128 + lds_chunk_off(v >> 3, kc)) = rb[j];
+                    for (int e = 0; e < EPC; ++e) v[e] = to_f32<T>(c[e]) * ssr[2 * e] + ssr[2 * e + 1];
+                    if (silu) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[e] = silu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) c[e] = from_f32<T>(v[e]);
+                }
+                *(chunk_t*)(Hs + lds_chunk_off2(hp, kc)) = c;
+            }
         }
     };
 
@@ -130,79 +174,186 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const i2i_igemm_param
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: slab 0 halo + step 0 weights ----
-    if (has_gn) load_ss(0);
-#pragma unroll
-    for (int j = 0; j < HPT; ++j) halo_store(0, j, halo_load(0, j));
-    b_load(0);
-    b_store(0);
-    __syncthreads();
+    const int nslab = cin / CK;
 
-    for (int slab = 0; slab < nslab; ++slab) {
-        const int hb = slab & 1;
+    // ---- prologue: weights of steps 0..2 and the slab's GN constants by DMA, halo of slab 0 through registers ----
+    b_dma(0, 0, 0);
+    b_dma(0, 1, 1);
+    b_dma(0, 2, 2);
+    if (has_gn) ss_dma(0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {          // fully unrolled: tap, dy, dx and every h_off[] index are constants
-            const int step = slab * 9 + tap;
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const int bb = step & 1;
-            const bool more = step + 1 < nstep;
-            // -- issue next step's global loads: weights always, one halo chunk of the NEXT slab on taps 0..HPT-1
-            if (more) b_load(step + 1);
-            const bool halo_pf = (tap < HPT) && (slab + 1 < nslab);
-            if (tap < HPT) {
-                if (halo_pf) {
-                    if (tap == 0 && has_gn) load_ss(slab + 1);   // previous slab's halo is complete: ssr is free
-                    rh = halo_load(slab + 1, tap < HPT ? tap : 0);
-                }
-            }
-            // -- MFMAs of this (slab, tap): A = halo rows (ty+dy, dx .. dx+15), B = weight slab
-            {
-                const char* Hb = Hs + hb * HALO * 128;
-                const char* Bb = Bs + bb * BN * 128;
+    for (int j = 0; j < HPT; ++j) halo_load(0, j);
+    wait_vmcnt<0>();
+    lds_barrier();
+    halo_store_all();
+    lds_barrier();
+
+    // ---- per-lane LDS read offsets, all precomputed so that every fragment read is "register + immediate":
+    // pixel fragment row = W + c + lr with W = wm*FM*18 (wave) and c = (i+dy)*18 + dx (compile time).  The
+    // swizzle depends on (W + lr + c) mod 8 only, i.e. on c mod 8: eight per-lane bases x_off[c & 7] (and the
+    // same with chunk bit 2 flipped, one v_xor, for the second k-group); the row part of c enters as the
+    // immediate c * 128 since x_off[m] is built for row u = W + lr alone.
+    int x_off[8];
+    {
+        const int u = wm * FM * HW2 + lr;
 #pragma unroll
-                for (int kg = 0; kg < 2; ++kg) {
-                    chunk_t af[FM], bf[FN];
+        for (int m = 0; m < 8; ++m) x_off[m] = u * 128 + ((lq ^ lds_swz2(u + m)) << 4);
+    }
+    // weight fragment row = wn*WTN + j*16 + lr (swizzle independent of j): base of buffer 0, k-group 0
+    const int w_off = lds_chunk_off2(wn * WTN + lr, lq) + HALO * 128;
+
+    // ---- the step pipeline.  A step = one (slab, tap) = 2 k-groups x FM tile rows = 2*FM "row groups" of FN
+    // MFMAs each.  Fragment reads run AHEAD of the MFMAs that use them, across k-groups and across the
+    // step barrier:
+    //   xq[4]  rotating pixel fragments, slot g % 4 for row group g, read PD groups ahead;
+    //   w0[FN] weights of k-group 0, re-read for the NEXT step during this step's k-group 1 (legal: the
+    //          weight slab of step s+1 landed and was barrier-published at the end of step s-1, see below);
+    //   w1[FN] weights of k-group 1, read during k-group 0.
+    // The schedule is pinned per row group with sched_group_barrier ({reads} then {FN MFMAs}) so the list
+    // scheduler neither hoists the whole step's 24 reads (VGPR blow-up) nor sinks them next to their use.
+    // Weight DMA runs two steps ahead into a 3-deep ring: step s issues slab s+2 into buffer (tap+2) % 3
+    // (last read in step s-1), waits for it with vmcnt(0) before the barrier that ends step s.
+    chunk_t xq[4], w0[FN], w1[FN];
+    constexpr int NG = 2 * FM;                       // row groups per step
+    static_assert(NG % 4 == 0 && PD >= 1 && PD <= 3, "xq rotation (4 slots) must close over a step");
+    auto xf_read = [&](int tapv, int g) __attribute__((always_inline)) -> chunk_t {   // pixel fragment of row group g
+        const int dy = tapv / 3, dx = tapv % 3, kg = g / FM, i = g % FM;
+        const int c = (i + dy) * HW2 + dx;
+        return *(const chunk_t*)(i2i_smem + (x_off[c & 7] ^ (kg * 64)) + c * 128);
+    };
+    auto wf_read = [&](int tapv, int kg, int j) __attribute__((always_inline)) -> chunk_t {
+        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + (tapv % 3) * BN * 128 + j * 2048));
+    };
+
+    // One row group g of step `tap`: its prefetch reads, then its FN MFMAs (schedule pinned in that order).
+    auto row_group = [&](auto tapc, auto gc, bool more) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value, g = decltype(gc)::value;
+        constexpr int kg = g / FM, i = g % FM;
+        constexpr int WPG = (FN + FM - 1) / FM;       // weight fragments fetched per row group
+        constexpr int j0 = i * WPG, nw = (j0 >= FN) ? 0 : ((j0 + WPG <= FN) ? WPG : FN - j0);
+        constexpr bool xpre = (g + PD < NG) || (tap < 8);
+        // pixel fragment PD row groups ahead (next step's first PD at the tail; not across a slab hand-over)
+        if constexpr (g + PD < NG) xq[(g + PD) % 4] = xf_read(tap, g + PD);
+        else if constexpr (tap < 8) xq[(g + PD) % 4] = xf_read(tap + 1, g + PD - NG);
+        // weight fragments: k-group 1 of this step during k-group 0, k-group 0 of the next step during k-group 1
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        const int hp = (wm * FM + i + dy) * HW2 + dx + lr;
-                        af[i] = *(const chunk_t*)(Hb + lds_chunk_off(hp, kg * 4 + lq));
-                    }
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) bf[j] = *(const chunk_t*)(Bb + lds_chunk_off(wn * WTN + j * 16 + lr, kg * 4 + lq));
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(af[i], bf[j], acc[i][j]);
-                }
-            }
-            // -- land the prefetched data in the other buffers
-            if (more) b_store(bb ^ 1);
-            if (tap < HPT) {
-                if (halo_pf) halo_store(hb ^ 1, tap < HPT ? tap : 0, rh);
-            }
-            __syncthreads();
+        for (int t = 0; t < nw; ++t) {
+            if constexpr (kg == 0) w1[j0 + t] = wf_read(tap, 1, j0 + t);
+            else if (more) w0[j0 + t] = wf_read(tap + 1, 0, j0 + t);
         }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], xq[g % 4], acc[i][j]);
+        if constexpr (nw + (xpre ? 1 : 0) > 0) __builtin_amdgcn_sched_group_barrier(0x100, nw + (xpre ? 1 : 0), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FN * MPC, 0);
+    };
+
+    // Step s = (slab, tap).  Its ONE barrier P_s sits between the two k-groups:
+    //   weight slab B[s] (ring buffer tap % 3) is read between P_{s-1} and P_s  (w0 during k-group 1 of step
+    //   s-1, w1 during k-group 0 of step s), so it must be published by P_{s-1} and its buffer is free after
+    //   P_s: the DMA of B[s+3] is issued right after P_s and waited for at P_{s+2} with a COUNTED vmcnt that
+    //   leaves the batch issued after P_{s+1} in flight -- two full steps of latency cover, never vmcnt(0)
+    //   in steady state.
+    constexpr int DMA_OPS = (NPIECE % NW == 0) ? BPW : 0;     // DMA instructions every wave issues per batch
+    auto nh = [](int t) constexpr { return (t >= 0 && t < HPT ? 1 : 0) + (t + 9 < HPT && t >= 0 ? 1 : 0); };
+    auto step = [&](int slab, bool next_slab, auto tapc) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value;
+        const bool more = tap < 8 || next_slab;           // another step follows
+        if (tap == 7 && next_slab && has_gn) ss_dma(slab + 1);   // Ss was last read at the previous hand-over
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (tap == 0) {                         // first step of a slab: the halo image is new
+#pragma unroll
+            for (int g = 0; g < PD; ++g) xq[g] = xf_read(0, g);
+            __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+        }
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, gc, more); });
+        __builtin_amdgcn_sched_barrier(0);
+        // -- P_s: publish B[s+1].  Outstanding VMEM ops allowed = the batch issued after P_{s-1}
+        //    (DMA of B[s+2] + the halo loads of tap-1), if that batch exists; tap 0 follows a full drain.
+        if constexpr (tap == 0) {
+            wait_vmcnt<0>();
+        } else {
+            if (next_slab) wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+            else if (tap + 2 < 9) wait_vmcnt<DMA_OPS>();
+            else wait_vmcnt<0>();
+        }
+        lds_barrier();
+        // -- window after P_s: DMA of B[s+3] into the buffer just released, next slab's halo into registers
+        if (tap + 3 < 9) b_dma(slab, tap + 3, tap % 3);
+        else if (next_slab) b_dma(slab + 1, tap + 3 - 9, tap % 3);
+        if (next_slab) {
+            if constexpr (tap < HPT) halo_load(slab + 1, tap);
+            if constexpr (tap + 9 < HPT) halo_load(slab + 1, tap + 9);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8 && next_slab) {                      // halo hand-over: everyone is done reading Hs
+            lds_barrier();
+            halo_store_all();
+            lds_barrier();
+        }
+    };
+
+    // first weights of the first step (every later step finds w0 preloaded by its predecessor)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
+    for (int slab = 0; slab < nslab; ++slab) {
+        const bool next_slab = slab + 1 < nslab;
+        step(slab, next_slab, ic<0>{});
+        step(slab, next_slab, ic<1>{});
+        step(slab, next_slab, ic<2>{});
+        step(slab, next_slab, ic<3>{});
+        step(slab, next_slab, ic<4>{});
+        step(slab, next_slab, ic<5>{});
+        step(slab, next_slab, ic<6>{});
+        step(slab, next_slab, ic<7>{});
+        step(slab, next_slab, ic<8>{});
     }
 
-    // ---- epilogue: alpha, bias, residual, store (row = tile row wm*FM+i, pixel tx = 4*lq + r) ----
+    // ---- epilogue: lane holds channels n = .. + 4*lq + (0..3) of pixel (oy, tx0 + lr): alpha, bias, residual,
+    // one 8-byte (fp32: 16-byte) store per fragment
     const T* __restrict__ res = (const T*)p.res;
+    const int ox = tx0 + lr;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int oy = ty0 + wm * FM + i;
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + lq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + lr;
-            if (n < p.N && oy < p.ho) {
-                const float bn = (p.bias_mode == 1) ? p.bias[n] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int oy = ty0 + wm * FM + i;
+            if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
+            const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r];
+            if (n + 3 < p.N) {
+                if (res) {
+                    typedef T tx4 __attribute__((ext_vector_type(4)));
+                    const tx4 rv = *(const tx4*)(res + m * p.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rv[r]);
+                }
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.c + m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    typedef T tx4 __attribute__((ext_vector_type(4)));
+                    tx4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                    *(tx4*)((T*)p.c + m * p.ldc + n) = o;
+                }
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ox = tx0 + lq * 4 + r;
-                    if (ox < p.wo) {
-                        const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
-                        float v = p.alpha * acc[i][j][r] + bn;
-                        if (res) v += to_f32<T>(res[m * p.ldr + n]);
-                        if (p.out_f32) ((float*)p.c)[m * p.ldc + n] = v;
-                        else ((T*)p.c)[m * p.ldc + n] = from_f32<T>(v);
+                    if (n + r < p.N) {
+                        float t = v[r];
+                        if (res) t += to_f32<T>(res[m * p.ldr + n + r]);
+                        if (p.out_f32) ((float*)p.c)[m * p.ldc + n + r] = t;
+                        else ((T*)p.c)[m * p.ldc + n + r] = from_f32<T>(t);
                     }
                 }
             }
@@ -210,19 +361,37 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const i2i_igemm_param
     }
 }
 
-template <typename T, int BN, int WM, int WN>
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
 int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
     const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN));
-    const size_t smem = 2 * (HALO + BN) * 128;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, WN>), dim3(tiles), dim3(256), smem, s, p);
+    const size_t smem = ((TH + 2) * HW2 + 3 * BN) * 128 + 512;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
     return i2i::check_launch("conv3x3_halo");
 }
 
+// tile ids (i2i_igemm_params.tile): 10 = auto; 11..19 force one configuration (tests / tuning)
 template <typename T>
 int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
-    if (p.N <= 16) return launch_halo<T, 16, 4, 1>(p, s);
-    if (p.N <= 64) return launch_halo<T, 64, 2, 2>(p, s);
-    return launch_halo<T, 128, 2, 2>(p, s);
+    int cfg = p.tile;
+    if (cfg == 0 || cfg == 10) {
+        const bool tall = p.ho >= 16;
+        if (p.N <= 16) cfg = 16;
+        else if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64)) cfg = tall ? 14 : 15;
+        else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles.md)
+        else cfg = (p.c0 + p.c1 <= 256) ? 17 : 13;
+    }
+    switch (cfg) {
+        case 11: return launch_halo<T, 16, 128, 2, 2, 2, 1>(p, s);   // 4 waves x (8 rows x 64 ch), 1 workgroup / CU
+        case 12: return launch_halo<T, 16, 128, 4, 2, 2, 2>(p, s);   // 8 waves x (4 rows x 64 ch), 1 workgroup / CU
+        case 13: return launch_halo<T, 8, 128, 2, 2, 2, 2>(p, s);    // 4 waves x (4 rows x 64 ch), 2 workgroups / CU
+        case 14: return launch_halo<T, 16, 64, 2, 2, 2, 2>(p, s);
+        case 15: return launch_halo<T, 8, 64, 2, 2, 2, 2>(p, s);
+        case 16: return launch_halo<T, 8, 16, 4, 1, 2, 2>(p, s);
+        case 17: return launch_halo<T, 8, 128, 2, 2, 3, 2>(p, s);    // as 13, prefetch distance 3
+        case 18: return launch_halo<T, 16, 128, 4, 2, 3, 2>(p, s);   // as 12, prefetch distance 3
+        case 19: return launch_halo<T, 16, 128, 2, 2, 3, 1>(p, s);   // as 11, prefetch distance 3
+    }
+    return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3: unknown tile config %d", cfg);
 }
 
 }  // namespace
@@ -233,8 +402,9 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
     const int ck = (dtype == I2I_F32) ? 32 : 64;
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2) return false;
     if (p.c0 % ck || p.c1 % ck || (p.c0 + p.c1) < ck) return false;
-    if (p.wo < TW || p.ho < TH) return false;
+    if (p.wo < TW || p.ho < 8) return false;
     if (p.ho != (p.hin << p.ups) || p.wo != (p.win << p.ups)) return false;
+    if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     return true;
 }
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s) {

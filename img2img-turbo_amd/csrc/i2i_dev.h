@@ -60,7 +60,8 @@ __device__ __forceinline__ f32x4 mma_chunk(f16x8 a, f16x8 b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the IEEE division sequence costs ~10 more VALU per element)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // LDS tile geometry common to A and B tiles: rows of 128 bytes = 8 chunks; chunk kc of row r is stored
@@ -68,6 +69,37 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // chunk 4*kg + (l>>4)) touches 16 distinct 16-byte slots in each of its four 16-lane service groups
 // (cdna_hip_programming.md section 2 / T2), and the 8-lane ds_write_b128 groups stay conflict-free.
 __device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
+
+// Offset-robust variant: chunk kc of row r at physical chunk kc ^ (((r >> 1) & 3) << 1).  A fragment read of
+// 16 CONSECUTIVE rows starting at ANY row (the shifted halo rows of the 3x3 taps) stays conflict-free in all
+// four ds_read_b128 service groups (brute-forced over every start with tools/lds_bank_model.py; the 3-bit
+// XOR above is 2-way conflicted for starts that are not multiples of 4).
+__device__ __forceinline__ int lds_swz2(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int lds_chunk_off2(int row, int kc) { return row * 128 + ((kc ^ lds_swz2(row)) << 4); }
+
+// ---- explicit synchronisation for LDS-DMA pipelines (cdna_hip_programming.md section 5: raw s_barrier +
+// counted waits; __syncthreads() would drain the DMA queue with vmcnt(0) at every barrier).
+// The CPU emulator (tests/emu, I2I_EMU) executes copies synchronously, so the waits are no-ops there.
+#ifdef I2I_EMU
+__device__ __forceinline__ void wait_lgkm0() {}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {}
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) { emu::global_load_lds16(g, lds_wave_base); }
+#else
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// global_load_lds_dwordx4: 16 bytes per lane, global address per lane, LDS destination = wave-uniform base
+// + lane * 16 (M0); no VGPR round trip, no ds_write.
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+// workgroup barrier that orders LDS traffic only (the caller places the vmcnt wait it needs)
+__device__ __forceinline__ void lds_barrier() {
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    wait_lgkm0();
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

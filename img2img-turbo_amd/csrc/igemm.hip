@@ -294,8 +294,9 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
-    if (p.tile == 10 && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile 10 (halo conv) not applicable");
-    if ((p.tile == 0 || p.tile == 10) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
+    const bool halo_forced = p.tile >= 10 && p.tile <= 19;
+    if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
+    if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     switch (dtype) {
         case I2I_F32: return launch_t<float>(p, s);
         case I2I_BF16: return launch_t<__bf16>(p, s);

@@ -96,8 +96,15 @@ template <class T> static inline T __shfl(T v, int lane, int = 64) { return emu_
 template <class T> static inline T __shfl_down(T v, int d, int = 64) { return emu_shfl_generic(v, d, 2); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl_generic(v, 0, 1); }
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
+namespace emu {
+// global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; executed synchronously here.
+static inline void global_load_lds16(const void* g, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * lane_id(), g, 16);
+}
+}  // namespace emu
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 // ---------------------------------------------------------------- MFMA (gfx950 layouts)
 typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
@@ -198,6 +205,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 
 // ---------------------------------------------------------------- runtime stubs used by capi

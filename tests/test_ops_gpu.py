@@ -72,3 +72,15 @@ def test_halo_conv(gpu_lib, dtype):
     oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=64, cout=64, h=16, w=16, ups=1, tile=10)
     oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cin2=64, cout=128, h=16, w=32, gn=True, act=1, groups=32, tile=10)
     oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=3, h=32, w=32, gn=True, act=1, groups=32, tile=10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19])
+def test_halo_conv_every_tile_config(gpu_lib, cfg):
+    """Every conv3x3.hip tile configuration on the real LDS-DMA path (the emulator copies synchronously, so
+    only the GPU run can see a missing wait): ragged planes, 2-4 slabs, GN+SiLU, residual, concat, upsample."""
+    cout = 3 if cfg == 16 else 200
+    for dtype in (torch.bfloat16, torch.float32):
+        oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=cout, h=40, w=56, gn=True, act=1, groups=32, res=(cfg != 16), tile=cfg)
+        oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=64, cin2=64, cout=cout, h=33, w=17, gn=True, act=1, groups=32, tile=cfg)
+        oc.check_conv(gpu_lib, "cuda", dtype, n=3, cin=64, cout=cout, h=16, w=24, ups=1, tile=cfg)
