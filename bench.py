@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 F_ALG = {512: 4.477e12, 1024: 20.22e12}   # algorithmic FLOP / image
 PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 CPU_BASELINE_THREADS = 16
+PER_OP_PATH = None
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
@@ -57,6 +58,11 @@ def kernel_roofline(plan, dtype_name, reps=2):
         f[0] += t
         f[1] += fl
         f[2] += 1
+    if PER_OP_PATH:
+        rows = sorted(((t, label, opc, fl) for (opc, _dt, _p, label), t, fl in zip(plan.prog.ops, ms, plan.op_flops)), reverse=True)
+        with open(PER_OP_PATH, "w") as f:
+            for t, label, opc, fl in rows:
+                f.write("%8.4f ms  %7.1f TF  op%-2d %s\n" % (t, fl / (t * 1e-3) / 1e12 if t > 0 else 0.0, opc, label))
     t3, f3, n3 = fam["igemm_conv3x3"]
     achieved = f3 / (t3 * 1e-3) / 1e12
     peak = PEAK_TF[dtype_name]
@@ -97,7 +103,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
     a = ap.parse_args()
+    global PER_OP_PATH
+    PER_OP_PATH = a.per_op
 
     from img2img_turbo_amd import dp
     from img2img_turbo_amd.arch import SD_TURBO_UNET, SD_TURBO_VAE, TINY_UNET, TINY_VAE

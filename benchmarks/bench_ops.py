@@ -35,6 +35,13 @@ SHAPES = [  # (name, cin, cout, H, W, ks, stride, ups, gn)
     ("unet lin 320->2560 T4096", 320, 2560, 64, 64, 1, 1, 0, 0),
     ("unet lin 1280->1280 T256", 1280, 1280, 16, 16, 1, 1, 0, 0),
     ("vae skip 128->256@512 1x1", 128, 256, 512, 512, 1, 1, 0, 0),
+    ("unet lin 320->320 T4096", 320, 320, 64, 64, 1, 1, 0, 0),
+    ("unet lin 1280->320 T4096", 1280, 320, 64, 64, 1, 1, 0, 0),
+    ("unet lin 640->5120 T1024", 640, 5120, 32, 32, 1, 1, 0, 0),
+    ("unet lin 2560->640 T1024", 2560, 640, 32, 32, 1, 1, 0, 0),
+    ("unet lin 1280->10240 T256", 1280, 10240, 16, 16, 1, 1, 0, 0),
+    ("unet lin 5120->1280 T256", 5120, 1280, 16, 16, 1, 1, 0, 0),
+    ("vae lin 512->1024 T4096", 512, 1024, 64, 64, 1, 1, 0, 0),
 ]
 
 
@@ -46,6 +53,8 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--out", default="gpurun_out/bench_ops.json")
     ap.add_argument("--only", default="", help="substring filter on shape names")
+    ap.add_argument("--splitk", default="0", help="comma list of split-K factors to try (LDS-DMA igemm)")
+    ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = 157.3 if a.dtype == "f32" else 2500.0
@@ -62,12 +71,14 @@ def main():
         coutp = (cout + 7) // 8 * 8
         out = torch.empty(B, ho, wo, coutp, device=dev, dtype=dt)
         bias = torch.randn(cout, device=dev)
+        gn = 0 if a.nogn else gn
         ss = torch.randn(B, cin, 2, device=dev) if gn else None
-        for tile in [int(t) for t in a.tiles.split(",")]:
+        for tile, sk in [(int(t), int(k)) for t in a.tiles.split(",") for k in a.splitk.split(",")]:
+            ws = torch.empty(sk * B * ho * wo * cout, device=dev) if sk > 1 else None
             prog = K.Program()
             for _ in range(a.iters + 1):
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
-                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile), dt))
+                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws), dt))
             prog.freeze()
             try:
                 ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]
@@ -77,9 +88,9 @@ def main():
             t = sorted(ms)[len(ms) // 2]
             fl = 2.0 * B * ho * wo * cout * ks * ks * cin
             tf = fl / (t * 1e-3) / 1e12
-            rec = dict(name=name, tile=tile, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
+            rec = dict(name=name, tile=tile, splitk=sk, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
             res.append(rec)
-            print("%-32s tile %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (name, tile, t, tf, 100 * tf / peak), flush=True)
+            print("%-32s tile %d sk %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (name, tile, sk, t, tf, 100 * tf / peak), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)

@@ -27,7 +27,8 @@ class IgemmParams(C.Structure):
                 ("bias", vp), ("bias_mode", i32), ("alpha", f32),
                 ("res", vp), ("ldr", i32), ("r_bs_b", i64), ("r_bs_h", i64),
                 ("c", vp), ("ldc", i32), ("c_bs_b", i64), ("c_bs_h", i64),
-                ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32)]
+                ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32),
+                ("splitk", i32), ("ws", vp)]
 
 
 class GnStatsParams(C.Structure):
@@ -37,7 +38,8 @@ class GnStatsParams(C.Structure):
 
 
 class GnApplyParams(C.Structure):
-    _fields_ = [("x", vp), ("y", vp), ("ss", vp), ("nimg", i32), ("hw", i32), ("c", i32), ("act", i32)]
+    _fields_ = [("x", vp), ("y", vp), ("ss", vp), ("nimg", i32), ("hw", i32), ("c", i32), ("act", i32),
+                ("ldx", i32), ("ldy", i32), ("ss_ld", i32), ("ss_off", i32)]
 
 
 class LayerNormParams(C.Structure):
@@ -156,7 +158,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 1:
+        if L.i2i_abi_version() != 2:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

@@ -1,0 +1,429 @@
+// LDS-DMA implicit GEMM for gfx950: the contraction kernel behind every nn.Linear / 1x1 conv / batched matmul
+// of the forward, and behind the 3x3 convolutions the halo kernel does not take (stride 2, planes smaller
+// than a halo tile, i.e. the 8x8 and 16x16 levels of the UNet).  Same contract as igemm.hip
+// (C[m][n] = epilogue(alpha * sum_k A[m][k] B[n][k]), A gathered on the fly from NHWC), different engine:
+//
+//   * BOTH operands reach LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write, no VALU on the data):
+//     a K step (64 halves / 32 floats) of the A tile [BM rows] and the B tile [BN rows] is 128 B per row;
+//     each wave owns (BM+BN)/8/NW one-KiB pieces, lane -> (row, physical chunk), the per-lane SOURCE address
+//     carries the XOR swizzle (and the im2col tap / padding: out-of-image taps read a 16-byte zero block).
+//   * 3-deep stage ring, DMA issued three steps ahead right after the step barrier that frees the stage, and
+//     waited for two steps later with a counted vmcnt (never 0 in steady state).
+//   * one raw s_barrier per K step, placed between the two k-groups; fragment reads run ahead of the MFMAs
+//     that use them (across k-groups and across the barrier), schedule pinned with sched_group_barrier.
+//   * MFMA operands swapped (A-operand = weight rows) so a lane owns 4 consecutive n of one m: bias,
+//     residual, GEGLU and the store are 8-byte (fp32 16-byte) vectors.
+//   * split-K (grid z) for the weight-streaming shapes (M = B*64 pixels x K = 9*2560): fp32 partial slabs +
+//     a reduce kernel that applies the epilogue; deterministic (fixed summation order).
+// GroupNorm prologues are NOT handled here (the planner materialises act(GN(x)) for the small planes that
+// take this path); igemm.hip remains the register-staged fallback for everything this kernel declines.
+#include "i2i_dev.h"
+#include "launch.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};   // DMA source of padding chunks
+
+template <int V> struct ic { static constexpr int value = V; };
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(ic<N - 1>{});
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_igemm_params p) {
+    constexpr int NW = WM * WN;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int MPC = (EPC == 4) ? 4 : 1;
+    constexpr int PA = BM / 8, PB = BN / 8, PPW = (PA + PB) / NW;     // one-KiB DMA pieces per stage / per wave
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && (PA + PB) % NW == 0, "");
+    typedef typename Elem<T>::chunk_t chunk_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // XCD-aware tile order (workgroup b -> XCD b % 8): each XCD gets a contiguous run of tiles, n fastest, so
+    // the tiles that share an A row block meet in one L2.
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y, split = blockIdx.z;
+    const int zb = z / p.zh_count, zh = z % p.zh_count;
+
+    const int64_t a_off = (int64_t)zb * p.a_bs_b + (int64_t)zh * p.a_bs_h;
+    const char* a0 = (const char*)((const T*)p.a0 + a_off);
+    const char* a1 = p.a1 ? (const char*)((const T*)p.a1 + a_off) : nullptr;
+    const char* bw = (const char*)((const T*)p.b + (int64_t)zb * p.b_bs_b + (int64_t)zh * p.b_bs_h);
+    const char* zero = (const char*)g_zero16;
+    const int cin = p.c0 + p.c1;
+    const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
+    const bool gather = p.ks != 1 || p.stride != 1 || p.ups != 0 || p.pad != 0;
+
+    // ---- K range of this split ----
+    const int nk = (p.K + BK - 1) / BK;
+    const int nsp = p.splitk > 1 ? p.splitk : 1;
+    const int per = (nk + nsp - 1) / nsp;
+    const int s_begin = split * per;
+    const int s_end = (s_begin + per < nk) ? s_begin + per : nk;
+
+    // ---- this wave's DMA pieces: pc = wave + q*NW; pc < PA -> A rows pc*8.., else B rows (pc-PA)*8.. ----
+    // per lane: row = 8*piece + (lane>>3), physical chunk lane&7 holds source chunk (lane&7) ^ swz(row)
+    unsigned pc_off[PPW];          // A: pixel index (GEMM row / image origin), B: byte offset of (row, source chunk)
+    int pc_y[PPW], pc_x[PPW];      // gather only: input coordinates of tap (0,0) for an A row; y = INT_MIN/2: row >= M
+    unsigned pc_chunk[PPW];        // source chunk index (for the K tail test)
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pc = wave + q * NW;
+        const int r8 = lane >> 3;
+        if (pc < PA) {
+            const int row = pc * 8 + r8;
+            const int sc = (lane & 7) ^ lds_swz2(row);
+            const int m = m0 + row;
+            pc_chunk[q] = sc;
+            if (!gather) {
+                pc_off[q] = (unsigned)(m < p.M ? m : 0);                  // row (= pixel) index; the two sources may differ in lda
+                pc_y[q] = m < p.M ? 0 : -(1 << 28);
+                pc_x[q] = 0;
+            } else {
+                const int hw = p.ho * p.wo;
+                const int mm = m < p.M ? m : 0;
+                const int img = mm / hw, rem = mm - img * hw;
+                const int oy = rem / p.wo, ox = rem - oy * p.wo;
+                pc_off[q] = (unsigned)(img * p.hin * p.win);              // pixel index of the image origin
+                pc_y[q] = m < p.M ? oy * p.stride - p.pad : -(1 << 28);
+                pc_x[q] = ox * p.stride - p.pad;
+            }
+        } else {
+            const int row = (pc - PA) * 8 + r8;
+            const int sc = (lane & 7) ^ lds_swz2(row);
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;                                   // clamped rows feed columns that are never stored
+            pc_chunk[q] = sc;
+            pc_off[q] = (unsigned)(n * p.ldb + sc * EPC) * (unsigned)sizeof(T);
+            pc_y[q] = 0; pc_x[q] = 0;
+        }
+    }
+
+    auto dma_stage = [&](int s, int stage) __attribute__((always_inline)) {     // K step s -> ring slot `stage`
+        const int k0 = s * BK;
+        // wave-uniform decode of the step: tap (ky,kx), channel offset and source (cin % BK == 0 when ks == 3)
+        int tap = 0, ci0 = k0;
+        if (p.ks != 1) { tap = k0 / cin; ci0 = k0 - tap * cin; }
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        const bool src1 = ci0 >= p.c0;
+        const char* abase = src1 ? a1 + (size_t)(ci0 - p.c0) * sizeof(T) : a0 + (size_t)ci0 * sizeof(T);
+        const unsigned lda_b = (unsigned)(src1 ? p.lda1 : p.lda0) * (unsigned)sizeof(T);
+        char* dst = i2i_smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int pc = wave + q * NW;
+            const bool kok = k0 + (int)pc_chunk[q] * EPC < p.K;           // K tail (ks == 1 with K % BK != 0)
+            const char* src;
+            if (pc < PA) {
+                if (!gather) {
+                    src = (kok && pc_y[q] >= 0) ? abase + (pc_off[q] * lda_b + pc_chunk[q] * 16u) : zero;
+                } else {
+                    const int iy = pc_y[q] + ky, ix = pc_x[q] + kx;
+                    const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
+                    const unsigned pix = pc_off[q] + (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+                    src = ok ? abase + (pix * lda_b + pc_chunk[q] * 16u) : zero;
+                }
+            } else {
+                src = kok ? bw + (size_t)k0 * sizeof(T) + pc_off[q] : zero;
+            }
+            glds16(src, dst + pc * 1024);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane fragment offsets: "register + immediate" for every read (rows are 16-aligned here) ----
+    const int x_off = lds_chunk_off2(wm * WTM + lr, lq);                  // A rows (m):  + i*2048, ^64 for k-group 1
+    const int w_off = BM * 128 + lds_chunk_off2(wn * WTN + lr, lq);       // B rows (n):  + j*2048
+    // Two fragment register sets: {xa, w0} = k-group 0 of a stage, {xb, w1} = k-group 1.  A stage is READ
+    // only between the barrier that publishes it (P_{s-1}) and its own barrier P_s: phase A of step s
+    // (k-group 0 MFMAs) loads {xb, w1} of stage s; phase B (k-group 1 MFMAs, after P_s) loads {xa, w0} of
+    // stage s+1.  Every read is issued a whole phase before its first use, and nothing touches stage s after
+    // P_s, so the DMA of step s+3 can reuse its slot immediately.
+    chunk_t xa[FM], xb[FM], w0[FN], w1[FN];
+    auto xf_read = [&](int stage, int kg, int i) __attribute__((always_inline)) -> chunk_t {
+        return *(const chunk_t*)(i2i_smem + ((x_off ^ (kg * 64)) + stage * STAGE + i * 2048));
+    };
+    auto wf_read = [&](int stage, int kg, int j) __attribute__((always_inline)) -> chunk_t {
+        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + stage * STAGE + j * 2048));
+    };
+    constexpr int NL = FM + FN, LPG = (NL + FM - 1) / FM;     // fragment loads per phase / per row group
+
+    // Row group i of a phase: LPG fragment loads for the NEXT phase, then FN MFMAs of this one (order pinned).
+    auto row_group = [&](auto stc, auto kgc, auto ic_) __attribute__((always_inline)) {
+        constexpr int st = decltype(stc)::value, kg = decltype(kgc)::value, i = decltype(ic_)::value;
+        constexpr int lst = (kg == 0) ? st : (st + 1) % 3;    // stage the loads read: own k-group 1, or next stage's k-group 0
+        constexpr int l0 = i * LPG, l1 = (l0 + LPG < NL) ? l0 + LPG : NL;
+#pragma unroll
+        for (int l = l0; l < l1; ++l) {
+            if (l < FN) { if constexpr (kg == 0) w1[l] = wf_read(lst, 1, l); else w0[l] = wf_read(lst, 0, l); }
+            else        { if constexpr (kg == 0) xb[l - FN] = xf_read(lst, 1, l - FN); else xa[l - FN] = xf_read(lst, 0, l - FN); }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], kg == 0 ? xa[i] : xb[i], acc[i][j]);
+        if constexpr (l1 > l0) __builtin_amdgcn_sched_group_barrier(0x100, l1 - l0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FN * MPC, 0);
+    };
+    // Step s in ring slot st.  The DMA of step s+3 goes out right after P_s and is waited for at P_{s+2} with
+    // vmcnt(PPW), which leaves exactly the batch issued after P_{s+1} in flight: two steps of latency cover.
+    // (Past the last step phase B prefetches a stale stage; those fragments are never used.)
+    auto step = [&](int s, auto stc) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(stc, ic<0>{}, gc); });
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < s_end) wait_vmcnt<PPW>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        if (s + 3 < s_end) dma_stage(s + 3, decltype(stc)::value);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(stc, ic<1>{}, gc); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (s_begin < s_end) {
+        // ---- prologue: up to three stages in flight, drain, publish ----
+        dma_stage(s_begin, 0);
+        if (s_begin + 1 < s_end) dma_stage(s_begin + 1, 1);
+        if (s_begin + 2 < s_end) dma_stage(s_begin + 2, 2);
+        wait_vmcnt<0>();
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xa[i] = xf_read(0, 0, i);
+        for (int s = s_begin; s < s_end; s += 3) {
+            step(s, ic<0>{});
+            if (s + 1 < s_end) step(s + 1, ic<1>{});
+            if (s + 2 < s_end) step(s + 2, ic<2>{});
+        }
+    }
+
+    // ---- epilogue: lane owns n = nb + 4*lq + (0..3) of row m = mb + lr ----
+    const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
+    const int64_t r_off = (int64_t)zb * p.r_bs_b + (int64_t)zh * p.r_bs_h;
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    if (nsp > 1) {     // split-K: raw fp32 partials [split][M][N]; the reduce kernel applies the epilogue
+        float* ws = (float*)p.ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + lr;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + lq * 4;
+                if (m < p.M && n < p.N) {
+                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4*)(ws + (int64_t)m * p.N + n) = acc[i][j];
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) ws[(int64_t)m * p.N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+    const T* __restrict__ res = p.res ? (const T*)p.res + r_off : nullptr;
+    if (p.geglu) {
+        // B rows (and bias) are interleaved per 32: [16 value rows | 16 gate rows]; out col = n/2 block
+        if constexpr (FN >= 2) {
+#pragma unroll
+            for (int j = 0; j + 1 < FN; j += 2) {
+                const int nA = n0 + wn * WTN + j * 16 + lq * 4;           // packed column of the 4 values
+                const int nG = nA + 16;
+                const int no = (n0 + wn * WTN + j * 16) / 2 + lq * 4;     // output column of the 4 results
+                if (nG >= p.N) continue;
+                float bA[4] = {0.f, 0.f, 0.f, 0.f}, bG[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { bA[r] = p.bias[nA + r]; bG[r] = p.bias[nG + r]; }
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * WTM + i * 16 + lr;
+                    if (m >= p.M) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = p.alpha * acc[i][j][r] + bA[r];
+                        const float g = p.alpha * acc[i][j + 1][r] + bG[r];
+                        v[r] = a * gelu_erf_f(g);
+                    }
+                    if (res) {
+                        const tx4 rv = *(const tx4*)(res + (int64_t)m * p.ldr + no);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rv[r]);
+                    }
+                    tx4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                    *(tx4*)((T*)p.c + c_off + (int64_t)m * p.ldc + no) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + lq * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + lr;
+            if (m >= p.M) continue;
+            const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r] + bm;
+            if (n + 3 < p.N) {
+                if (res) {
+                    const tx4 rv = *(const tx4*)(res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rv[r]);
+                }
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.c + c_off + (int64_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    tx4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                    *(tx4*)((T*)p.c + c_off + (int64_t)m * p.ldc + n) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < p.N) {
+                        float t = v[r];
+                        if (res) t += to_f32<T>(res[(int64_t)m * p.ldr + n + r]);
+                        if (p.out_f32) ((float*)p.c + c_off)[(int64_t)m * p.ldc + n + r] = t;
+                        else ((T*)p.c + c_off)[(int64_t)m * p.ldc + n + r] = from_f32<T>(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K reduce: out = epilogue(alpha * sum_s ws[s][m][n]); fixed summation order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const i2i_igemm_params p) {
+    const int64_t total = (int64_t)p.M * p.N;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e0 >= total) return;
+    const float* ws = (const float*)p.ws;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.N & 3) == 0;
+    for (int s = 0; s < p.splitk; ++s) {
+        if (vec) {
+            const f32x4 t = *(const f32x4*)(ws + (int64_t)s * total + e0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += t[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (e0 + r < total) v[r] += ws[(int64_t)s * total + e0 + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t e = e0 + r;
+        if (e >= total) break;
+        const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
+        float t = p.alpha * v[r];
+        if (p.bias_mode == 1) t += p.bias[n];
+        else if (p.bias_mode == 2) t += p.bias[m];
+        if (p.res) t += to_f32<T>(((const T*)p.res)[(int64_t)m * p.ldr + n]);
+        if (p.out_f32) ((float*)p.c)[(int64_t)m * p.ldc + n] = t;
+        else ((T*)p.c)[(int64_t)m * p.ldc + n] = from_f32<T>(t);
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MINW>
+int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
+    const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
+    const unsigned nsp = p.splitk > 1 ? (unsigned)p.splitk : 1u;
+    // ring slots actually used: a split with fewer than 3 K steps needs fewer (short-K GEMMs are latency
+    // bound: less LDS = more workgroups per CU to overlap DMA latency, MFMAs and epilogue stores)
+    const int nk = (p.K + 8 * Elem<T>::EPC - 1) / (8 * Elem<T>::EPC);
+    const int per = (nk + (int)nsp - 1) / (int)nsp;
+    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * (BM + BN) * 128;
+    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW>), dim3(tiles, (unsigned)p.zcount, nsp), dim3(WM * WN * 64), smem, s, p);
+    int rc = i2i::check_launch("igemm_dma");
+    if (rc != I2I_OK || nsp == 1) return rc;
+    const int64_t total = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, p);
+    return i2i::check_launch("splitk_reduce");
+}
+
+// tile ids 20..29 (i2i_igemm_params.tile): 20 = auto
+template <typename T>
+int launch_dma_t(const i2i_igemm_params& p, hipStream_t s) {
+    int cfg = p.tile;
+    if (cfg == 0 || cfg == 20) {
+        if (p.M <= 2048) cfg = (p.N <= 64) ? 24 : 23;          // measured (profiles/): BM = 64 for the small-M shapes
+        else if (p.N <= 64) cfg = 22;
+        else cfg = 25;
+    }
+    switch (cfg) {
+        case 21: return launch_dma<T, 128, 128, 2, 2, 2>(p, s);   // 96 KiB ring, 1 workgroup / CU
+        case 22: return launch_dma<T, 128, 64, 2, 2, 2>(p, s);    // 72 KiB ring, 2 workgroups / CU
+        case 23: return launch_dma<T, 64, 128, 2, 2, 2>(p, s);    // small M (weight streaming), 72 KiB
+        case 24: return launch_dma<T, 64, 64, 2, 2, 2>(p, s);     // 48 KiB, 3 workgroups / CU
+        case 25: return launch_dma<T, 256, 128, 4, 2, 2>(p, s);   // 8 waves, 144 KiB
+    }
+    return i2i::fail(I2I_ERR_BAD_ARG, "igemm_dma: unknown tile config %d", cfg);
+}
+
+}  // namespace
+
+namespace i2i {
+// What the DMA engine takes: no GroupNorm prologue, slab-aligned taps, vector-aligned outputs, 32-bit offsets.
+bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
+    const int epc = (dtype == I2I_F32) ? 4 : 8, bk = 8 * epc;
+    const size_t sz = (dtype == I2I_F32) ? 4 : 2;
+    const int cin = p.c0 + p.c1;
+    if (p.gn_ss) return false;
+    if (p.ks != 1 && (cin % bk || p.c0 % bk)) return false;
+    if (p.ks == 1 && p.c1 && (p.c0 % bk)) return false;
+    if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
+    if ((p.c_bs_b | p.c_bs_h | p.r_bs_b | p.r_bs_h) & 3) return false;
+    if (((uintptr_t)p.c & 15) || ((uintptr_t)p.res & 7)) return false;
+    if (p.geglu && (p.N % 32)) return false;
+    const uint64_t a_bytes = (uint64_t)p.nimg * p.hin * p.win * (uint64_t)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * sz;
+    const uint64_t b_bytes = (uint64_t)p.N * p.ldb * sz;
+    if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
+    if (p.splitk > 1 && (!p.ws || p.zcount > 1 || p.geglu)) return false;
+    return true;
+}
+int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case I2I_F32: return launch_dma_t<float>(p, s);
+        case I2I_BF16: return launch_dma_t<__bf16>(p, s);
+        case I2I_F16: return launch_dma_t<_Float16>(p, s);
+    }
+    return fail(I2I_ERR_BAD_ARG, "igemm_dma: bad dtype");
+}
+}  // namespace i2i

@@ -22,6 +22,8 @@
 namespace i2i {
 bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype);   // conv3x3.hip
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s);
+bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.hip
+int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
 
 namespace {
@@ -297,6 +299,11 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     const bool halo_forced = p.tile >= 10 && p.tile <= 19;
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
+    // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)
+    const bool dma_forced = p.tile >= 20 && p.tile <= 29;
+    if (dma_forced && !i2i::igemm_dma_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (LDS-DMA igemm) not applicable", p.tile);
+    if ((p.tile == 0 || dma_forced) && i2i::igemm_dma_eligible(p, dtype)) return i2i::igemm_dma(p, dtype, s);
+    if (p.splitk > 1) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: split-K needs the LDS-DMA path (no GN prologue, aligned output, ws)");
     switch (dtype) {
         case I2I_F32: return launch_t<float>(p, s);
         case I2I_BF16: return launch_t<__bf16>(p, s);

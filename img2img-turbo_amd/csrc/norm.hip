@@ -128,19 +128,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const i2i_gn_apply_params
     constexpr int EPC = Elem<T>::EPC;
     const int64_t nchunk = (int64_t)p.nimg * p.hw * p.c / EPC;
     const int cpp = p.c / EPC;   // chunks per pixel
+    const int ldx = p.ldx ? p.ldx : p.c, ldy = p.ldy ? p.ldy : p.c;
+    const int ss_ld = p.ss_ld ? p.ss_ld : p.c;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / cpp;
         const int c = (int)(i - pix * cpp) * EPC;
         const int img = (int)(pix / p.hw);
-        chunk_t v = ((const chunk_t*)p.x)[i];
-        const float* ss = p.ss + ((int64_t)img * p.c + c) * 2;
+        chunk_t v = *(const chunk_t*)((const T*)p.x + pix * ldx + c);
+        const float* ss = p.ss + ((int64_t)img * ss_ld + p.ss_off + c) * 2;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float f = to_f32<T>(v[e]) * ss[2 * e] + ss[2 * e + 1];
             if (p.act == 1) f = silu_f(f);
             v[e] = from_f32<T>(f);
         }
-        ((chunk_t*)p.y)[i] = v;
+        *(chunk_t*)((T*)p.y + pix * ldy + c) = v;
     }
 }
 
@@ -247,7 +249,7 @@ extern "C" int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* strea
 
 extern "C" int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream) {
     if (!p || !p->x || !p->y || !p->ss) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: null pointer");
-    if (p->c % 8) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: c %% 8");
+    if (p->c % 8 || p->ldx % 8 || p->ldy % 8 || p->ss_off % 4 || ((uintptr_t)p->y & 15)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: c / ld / offsets must keep 16-byte chunks aligned");
     const int64_t n = (int64_t)p->nimg * p->hw * p->c / 8;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;

@@ -17,7 +17,7 @@ def ptr(t):
 
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
-         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0):
+         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None):
     """Implicit-GEMM conv / linear over NHWC sources.  ``w`` is packed [N][ks*ks*(c0+c1)]."""
     p = K.IgemmParams()
     c0 = x0.shape[-1] if c0 is None else c0
@@ -42,6 +42,7 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.ldc = ldc if ldc is not None else out.shape[-1]
     p.zcount, p.zh_count = 1, 1
     p.geglu, p.out_f32, p.tile = geglu, out_f32, tile
+    p.splitk, p.ws = splitk, ptr(ws)
     return K.OP_IGEMM, p
 
 
@@ -78,9 +79,12 @@ def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=
     return K.OP_GN_STATS, p
 
 
-def gn_apply(x, y, ss, *, nimg, hw, c, act):
+def gn_apply(x, y, ss, *, nimg, hw, c, act, ldx=0, ldy=0, ss_ld=0, ss_off=0, y_off=0):
+    """y[..., y_off:y_off+c] = act(x * scale + shift); ``y_off``/``ldy`` write a channel slice of a wider buffer."""
     p = K.GnApplyParams()
-    p.x, p.y, p.ss, p.nimg, p.hw, p.c, p.act = ptr(x), ptr(y), ptr(ss), nimg, hw, c, act
+    p.x, p.ss, p.nimg, p.hw, p.c, p.act = ptr(x), ptr(ss), nimg, hw, c, act
+    p.y = ptr(y) + y_off * y.element_size()
+    p.ldx, p.ldy, p.ss_ld, p.ss_off = ldx, ldy, ss_ld, ss_off
     return K.OP_GN_APPLY, p
 
 

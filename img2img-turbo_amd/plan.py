@@ -71,7 +71,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         if (H // 8) % 8 or (W // 8) % 8:
             raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
@@ -81,6 +81,7 @@ class ForwardPlan:
         self.dt = O.DT[dtype]
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
+        self.dma_small = dma_small   # non-halo GN convs: materialise GN and use the LDS-DMA igemm (+ split-K)
         self.ua, self.va = weights.unet_arch, weights.vae_arch
         vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
         if packers is None:
@@ -150,6 +151,21 @@ class ForwardPlan:
         self._pending_gn.append((op[1], "stats"))
         self._add(op, label or norm_name)
 
+    def _splitk(self, M, N, Kd):
+        """Split-K factor + fp32 slab for the weight-streaming shapes (few rows, K in the thousands); mirrors the
+        tile choice of launch_dma_t (csrc/gemm_dma.hip).  The slab goes back to the pool right after the op is
+        recorded: the program runs in order on one stream, so later ops may reuse it."""
+        bk = 32 if self.dtype == torch.float32 else 64
+        if Kd % bk:
+            return 0, None
+        bm = 64 if M <= 2048 else 128
+        bn = 128 if N > 64 else 64
+        tiles = -(-M // bm) * -(-N // bn)
+        sk = min(512 // max(tiles, 1), (Kd // bk) // 4, 16)
+        if sk < 2:
+            return 0, None
+        return sk, self.pool.get(sk * M * N, torch.float32)
+
     def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, asym=False, x1: Optional[Act] = None, gn=False, act=0,
              res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
              label="") -> Act:
@@ -169,19 +185,35 @@ class ForwardPlan:
         c1 = x1.c if x1 else 0
         assert pw["w"].shape[1] == ks * ks * (x.c + c1), (label, pw["w"].shape, ks, x.c, c1)
         x_in0, x_in1 = x, x1
-        fused = self.fuse_gn or x1 is not None     # the two-source (concat) case always applies GN in the gather
+        c0_eff, c1_eff = x.c, c1
+        epc = 4 if self.dtype == torch.float32 else 8
+        bk = 8 * epc
+        # mirrors conv3x3_halo_eligible (csrc/conv3x3.hip): those convolutions apply GN+SiLU while staging the halo
+        halo = (ks == 3 and stride == 1 and pad == 1 and not asym and not geglu and x.c % bk == 0 and c1 % bk == 0
+                and wo >= 16 and ho >= 8)
+        fused = gn and self.fuse_gn and (halo or not self.dma_small)
         if gn and not fused:
-            # unfused fallback: materialise act(GN(x)) first (single source only)
-            y = self.new(x.n, x.h, x.w, x.c)
-            op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act)
-            self._pending_gn.append((op[1], "apply"))
-            self._add(op, label + ".gn_apply")
-            x_in0 = y
+            # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
+            # UNet planes / 1x1 projections has no operand prologue, and the extra pass is over a few MB at most
+            ct = x.c + c1
+            y = self.new(x.n, x.h, x.w, ct)
+            for src, coff in ((x, 0), (x1, x.c)):
+                if src is None:
+                    continue
+                op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+                self._pending_gn.append((op[1], "apply"))
+                self._add(op, label + ".gn_apply")
+            x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
+        M, N, Kd = x.n * ho * wo, pw["n"], ks * ks * (x.c + c1)
+        splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
         op = O.conv(x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
-                    x1=x_in1.t if x_in1 else None, c0=x.c, c1=c1, lda0=x.c, lda1=c1, N=pw["n"],
-                    gn_ss=None, act=act if (gn and fused) else 0, bias=pw["b"], alpha=alpha,
-                    res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32)
-        if gn and fused:
+                    x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
+                    gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
+                    res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
+                    splitk=splitk, ws=ws)
+        if ws is not None:
+            self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
+        if fused:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
         fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
@@ -198,8 +230,11 @@ class ForwardPlan:
         out_cols = out_cols or n_out
         if out is None:
             out = self.pool.get(rows * out_cols, self.dtype)
+        splitk, ws = (0, None) if geglu else self._splitk(rows, pw["n"], cin)
         op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
-                    res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu)
+                    res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu, splitk=splitk, ws=ws)
+        if ws is not None:
+            self.pool.put(ws)
         self._add(op, label, 2 * rows * pw["n"] * cin)
         self.flops += 2 * rows * pw["n"] * cin
         return out

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 1
+#define I2I_ABI_VERSION 2
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2 } i2i_dtype;
 
@@ -82,7 +82,10 @@ typedef struct {
     int32_t zcount, zh_count;  /* grid z = zcount batches; zh_count heads per batch (>= 1) */
     int32_t geglu;             /* 1: B rows interleaved [a16|g16]; out[:, n/2] = a * gelu(g); ldc for N/2 */
     int32_t out_f32;           /* 1: store fp32 regardless of dtype (attention scores) */
-    int32_t tile;              /* 0 = auto; else forces a tile config id (tests / tuning) */
+    int32_t tile;              /* 0 = auto; else forces a kernel / tile config id (tests / tuning):
+                                  1-5 register-staged igemm, 10-19 halo conv3x3, 20-25 LDS-DMA igemm */
+    int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
+    void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.
@@ -96,9 +99,12 @@ typedef struct {
     float* ss;                                /* out [nimg][c0+c1][2] */
 } i2i_gn_stats_params;
 
-/* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Fallback used when fusion is disabled. */
+/* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its
+ * operand staging (LDS-DMA igemm on the small UNet planes, unfused VAE attention), and when fusion is disabled. */
 typedef struct {
     const void* x; void* y; const float* ss; int32_t nimg, hw, c, act;
+    int32_t ldx, ldy;          /* pixel strides in elements (0 = c): y may be a channel slice of a concat buffer */
+    int32_t ss_ld, ss_off;     /* ss is [nimg][ss_ld][2]; this tensor's channels start at ss_off (0,0 = c,0) */
 } i2i_gn_apply_params;
 
 /* LayerNorm over the last dim (F.layer_norm, eps 1e-5, affine). rows x c, c multiple of 8. */

@@ -60,7 +60,7 @@ def gn_scale_shift(x, groups, gamma, beta, eps):
 
 
 def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, stride=1, pad=1, ups=0,
-               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4):
+               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4, splitk=0):
     g = torch.Generator().manual_seed(seed)
     ct = cin + cin2
     x = torch.randn(n, ct, h, w, generator=g)
@@ -114,8 +114,10 @@ def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, st
     out = torch.full((n, ho, wo, coutp), float("nan"), dtype=dtype, device=device)
     rd = nhwc(r, dtype, coutp).to(device) if res else None
     bd = b.float().to(device) if bias else None
+    wsd = torch.full((splitk * n * ho * wo * cout,), float("nan"), device=device) if splitk > 1 else None   # keep alive
     opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=ks, stride=stride, pad=kpad, ups=ups,
-                       x1=x1, c0=c0p, c1=c1p, N=cout, gn_ss=ssd, act=act, bias=bd, alpha=alpha, res=rd, tile=tile)
+                       x1=x1, c0=c0p, c1=c1p, N=cout, gn_ss=ssd, act=act, bias=bd, alpha=alpha, res=rd, tile=tile,
+                       splitk=splitk, ws=wsd)
     run_op(lib, opcode, p, dtype, device)
     got = out.cpu().float()[..., :cout].permute(0, 3, 1, 2)
     assert torch.isfinite(got).all(), "non-finite output"
@@ -149,7 +151,7 @@ def check_geglu(lib, device, dtype, *, rows=70, cin=32, cff=64, seed=0, tile=0):
     return err
 
 
-def check_bgemm(lib, device, dtype, *, batch=2, heads=2, M=40, N=24, Kd=64, out_f32=1, seed=0):
+def check_bgemm(lib, device, dtype, *, batch=2, heads=2, M=40, N=24, Kd=64, out_f32=1, seed=0, tile=0):
     g = torch.Generator().manual_seed(seed)
     C = heads * Kd
     a = torch.randn(batch, M, C, generator=g).to(dtype)
@@ -158,7 +160,7 @@ def check_bgemm(lib, device, dtype, *, batch=2, heads=2, M=40, N=24, Kd=64, out_
     ad, bd = a.to(device), b.to(device)
     out = torch.full((batch, heads, M, N), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=device)
     opcode, p = O.bgemm(ad, bd, out, M=M, N=N, Kdim=Kd, lda=C, ldb=C, ldc=N, batch=batch, heads=heads,
-                        a_bs=(M * C, Kd), b_bs=(N * C, Kd), c_bs=(heads * M * N, M * N), alpha=0.5, out_f32=out_f32)
+                        a_bs=(M * C, Kd), b_bs=(N * C, Kd), c_bs=(heads * M * N, M * N), alpha=0.5, out_f32=out_f32, tile=tile)
     run_op(lib, opcode, p, dtype, device)
     err = rel_err(out.cpu(), ref)
     assert err < TOL[dtype], f"bgemm rel err {err}"

@@ -133,3 +133,34 @@ def test_halo_conv_every_tile_config(emu_lib, cfg):
 def test_halo_conv_f32_three_slabs_concat_upsample(emu_lib, cfg):
     oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=32, cin2=64, cout=40, h=18, w=16, gn=True, act=1, groups=8, tile=cfg)
     oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=64, cout=136, h=9, w=8, ups=1, tile=cfg)
+
+
+# ---- LDS-DMA implicit GEMM (gemm_dma.hip): tile 20 = auto, 21..25 force a configuration ----
+@pytest.mark.parametrize("cfg", [21, 22, 23, 24, 25])
+def test_dma_igemm_every_tile_config(emu_lib, cfg):
+    """Linear with a K tail (K % 64 != 0), ragged M and N, bias + residual; then a 3x3 stride-2 gather with padding."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=88, cout=72, h=9, w=23, ks=1, pad=0, res=True, alpha=0.7, tile=cfg)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=2, cin=64, cout=40, h=12, w=10, stride=2, pad=1, tile=cfg)
+
+
+def test_dma_igemm_gathers(emu_lib):
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=2, cin=32, cout=48, h=6, w=6, tile=20)                       # 3x3 s1 on a small plane
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=32, h=12, w=8, stride=2, asym_pad=True, tile=20)  # VAE F.pad(0,1,0,1)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=32, cout=32, h=5, w=6, ups=1, tile=20)                # Upsample2D gather
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=64, h=8, w=8, tile=20)              # 3x3 concat
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=32, cin2=64, cout=48, h=4, w=8, ks=1, pad=0, tile=20)  # 1x1 concat (shortcut)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dma_igemm_geglu_bgemm(emu_lib, dtype):
+    oc.check_geglu(emu_lib, "cpu", dtype, tile=20)
+    oc.check_geglu(emu_lib, "cpu", dtype, tile=21, cff=128, rows=200)
+    oc.check_bgemm(emu_lib, "cpu", dtype, tile=20)
+    oc.check_bgemm(emu_lib, "cpu", dtype, out_f32=0, tile=22)
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 5])
+def test_dma_igemm_splitk(emu_lib, splitk):
+    """Weight-streaming shape in miniature: few rows, long K (3x3 over 4 slabs = 36 steps), split over grid z."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=72, h=4, w=4, res=True, tile=23, splitk=splitk)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=96, cout=40, h=4, w=4, tile=24, splitk=splitk)

@@ -84,3 +84,25 @@ def test_halo_conv_every_tile_config(gpu_lib, cfg):
         oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=cout, h=40, w=56, gn=True, act=1, groups=32, res=(cfg != 16), tile=cfg)
         oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=64, cin2=64, cout=cout, h=33, w=17, gn=True, act=1, groups=32, tile=cfg)
         oc.check_conv(gpu_lib, "cuda", dtype, n=3, cin=64, cout=cout, h=16, w=24, ups=1, tile=cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [21, 22, 23, 24, 25])
+def test_dma_igemm_every_tile_config(gpu_lib, cfg):
+    """gemm_dma.hip on the real LDS-DMA path: K tails, ragged M/N, gathers, long K loops (ring wrap-around)."""
+    for dtype in (torch.bfloat16, torch.float32):
+        oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=328, cout=200, h=37, w=23, ks=1, pad=0, res=True, alpha=0.7, tile=cfg)
+        oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=136, h=24, w=20, stride=2, pad=1, tile=cfg)
+        oc.check_conv(gpu_lib, "cuda", dtype, n=3, cin=256, cout=72, h=8, w=8, res=True, tile=cfg)
+        oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=64, cin2=192, cout=96, h=16, w=16, ks=1, pad=0, tile=cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
+    oc.check_geglu(gpu_lib, "cuda", dtype, tile=20, rows=300, cin=320, cff=1280)
+    oc.check_bgemm(gpu_lib, "cuda", dtype, tile=20, M=300, N=77, Kd=64) if False else None
+    oc.check_bgemm(gpu_lib, "cuda", dtype, tile=20, M=300, N=76, Kd=64)
+    oc.check_bgemm(gpu_lib, "cuda", dtype, out_f32=0, tile=22, M=130, N=64, Kd=128)
+    for sk in (2, 6, 9):
+        oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=512, cout=200, h=8, w=8, res=True, tile=23, splitk=sk)
