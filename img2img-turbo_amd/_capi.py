@@ -28,13 +28,13 @@ class IgemmParams(C.Structure):
                 ("res", vp), ("ldr", i32), ("r_bs_b", i64), ("r_bs_h", i64),
                 ("c", vp), ("ldc", i32), ("c_bs_b", i64), ("c_bs_h", i64),
                 ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32),
-                ("splitk", i32), ("ws", vp)]
+                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32)]
 
 
 class GnStatsParams(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("c0", i32), ("c1", i32), ("ld0", i32), ("ld1", i32),
                 ("nimg", i32), ("hw", i32), ("groups", i32), ("eps", f32),
-                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp)]
+                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp), ("finalize_only", i32)]
 
 
 class GnApplyParams(C.Structure):
@@ -95,7 +95,7 @@ _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply"
              OP_SOFTMAX: "softmax", OP_ATTENTION: "attention", OP_NCHW_TO_NHWC: "to_nhwc",
              OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm"}
 
-EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_gn_stats",
+EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
            "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
@@ -153,6 +153,8 @@ class Library:
                      "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant"):
             getattr(L, name).argtypes = [vp, C.c_int, vp]
             getattr(L, name).restype = C.c_int
+        L.i2i_igemm_gn_parts.argtypes = [vp, C.c_int, C.c_int]
+        L.i2i_igemm_gn_parts.restype = C.c_int
         L.i2i_run.argtypes = [vp, C.c_int, vp]
         L.i2i_run_timed.argtypes = [vp, C.c_int, vp, vp]
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
@@ -169,6 +171,10 @@ class Library:
             raise I2IError("i2i error %d: %s" % (rc, self.lib.i2i_last_error().decode()))
 
     # ---- programs -------------------------------------------------------------------------------
+    def igemm_gn_parts(self, params, dtype_code, groups):
+        """Partial-sum slots per image the igemm op would write through gn_part (0 = its kernel cannot)."""
+        return int(self.lib.i2i_igemm_gn_parts(C.addressof(params), dtype_code, groups))
+
     def run(self, prog, stream=0):
         self.check(self.lib.i2i_run(C.addressof(prog.array), prog.n, vp(stream)))
 

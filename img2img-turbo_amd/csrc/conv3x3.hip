@@ -314,6 +314,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     // one 8-byte (fp32: 16-byte) store per fragment
     const T* __restrict__ res = (const T*)p.res;
     const int ox = tx0 + lr;
+    const bool do_stats = p.gn_part != nullptr;      // GroupNorm partial sums of the stored output (next layer's norm)
+    float gs[FN], gq[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * WTN + j * 16 + lq * 4;
@@ -345,6 +349,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
                     *(tx4*)((T*)p.c + m * p.ldc + n) = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = to_f32<T>(o[r]); gs[j] += f; gq[j] += f * f; }
+                    }
                 }
             } else {
 #pragma unroll
@@ -359,6 +367,42 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             }
         }
     }
+    // ---- GroupNorm partial sums: lane -> 16 pixels (shuffles) -> wave (LDS) -> workgroup -> one slot per group.
+    // Fixed reduction order: deterministic.  Only full 4-channel vectors were accumulated (host checks N % 4 == 0,
+    // dtype output, channels-per-group a multiple of 4 that divides the wave's channel span).
+    if (do_stats) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { gs[j] += __shfl_xor(gs[j], m); gq[j] += __shfl_xor(gq[j], m); }
+        lds_barrier();                                   // every wave is done with its fragments
+        float* st = (float*)i2i_smem;                    // [NW][FN*4 quads][2]
+        if (lr == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                st[((wave * FN + j) * 4 + lq) * 2 + 0] = gs[j];
+                st[((wave * FN + j) * 4 + lq) * 2 + 1] = gq[j];
+            }
+        }
+        lds_barrier();
+        const int groups = p.gn_part_groups, cpg = p.N / groups;
+        const int ng_tile = BN / cpg;
+        const int g = n0 / cpg + tid;
+        if (tid < ng_tile && g < groups) {
+            const int c0w = tid * cpg;                   // first channel of the group inside the n-tile
+            const int wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
+            float S = 0.f, Q = 0.f;
+            for (int wmm = 0; wmm < WM; ++wmm)
+                for (int q = q0; q < q0 + nq; ++q) {
+                    S += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 0];
+                    Q += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 1];
+                }
+            const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
+            float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
+            out[0] = S;
+            out[1] = Q;
+        }
+    }
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
@@ -370,16 +414,32 @@ int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
 }
 
 // tile ids (i2i_igemm_params.tile): 10 = auto; 11..19 force one configuration (tests / tuning)
-template <typename T>
-int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
+int halo_cfg(const i2i_igemm_params& p) {
     int cfg = p.tile;
     if (cfg == 0 || cfg == 10) {
         const bool tall = p.ho >= 16;
         if (p.N <= 16) cfg = 16;
         else if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64)) cfg = tall ? 14 : 15;
-        else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles.md)
+        else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles_bench_ops.log)
         else cfg = (p.c0 + p.c1 <= 256) ? 17 : 13;
     }
+    return cfg;
+}
+// (tile rows, channel tile, channels per wave) of a configuration
+void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
+    switch (cfg) {
+        case 11: case 19: *th = 16; *bn = 128; *wtn = 64; break;
+        case 12: case 18: *th = 16; *bn = 128; *wtn = 64; break;
+        case 13: case 17: *th = 8; *bn = 128; *wtn = 64; break;
+        case 14: *th = 16; *bn = 64; *wtn = 32; break;
+        case 15: *th = 8; *bn = 64; *wtn = 32; break;
+        default: *th = 8; *bn = 16; *wtn = 16; break;
+    }
+}
+
+template <typename T>
+int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
+    const int cfg = halo_cfg(p);
     switch (cfg) {
         case 11: return launch_halo<T, 16, 128, 2, 2, 2, 1>(p, s);   // 4 waves x (8 rows x 64 ch), 1 workgroup / CU
         case 12: return launch_halo<T, 16, 128, 4, 2, 2, 2>(p, s);   // 8 waves x (4 rows x 64 ch), 1 workgroup / CU
@@ -406,6 +466,16 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.ho != (p.hin << p.ups) || p.wo != (p.win << p.ups)) return false;
     if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     return true;
+}
+// GroupNorm partial-sum slots per image (= spatial tiles) the halo kernel writes for this op, 0 if it cannot:
+// needs dtype output, N % 4 == 0 and channels-per-group a multiple of 4 dividing the channels one wave owns.
+int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
+    if (!conv3x3_halo_eligible(p, dtype) || p.out_f32 || groups < 1 || p.N % groups || p.N % 4) return 0;
+    const int cpg = p.N / groups;
+    int th, bn, wtn;
+    halo_cfg_geometry(halo_cfg(p), &th, &bn, &wtn);
+    if (cpg % 4 || wtn % cpg) return 0;
+    return ((p.wo + TW - 1) / TW) * ((p.ho + th - 1) / th);
 }
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     switch (dtype) {

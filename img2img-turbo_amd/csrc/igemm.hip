@@ -22,6 +22,7 @@
 namespace i2i {
 bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype);   // conv3x3.hip
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s);
+int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.hip
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
@@ -296,6 +297,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
+    if (p.gn_part && !i2i::conv3x3_halo_gn_parts(p, dtype, p.gn_part_groups))
+        return i2i::fail(I2I_ERR_BAD_ARG, "igemm: gn_part requested but this op cannot produce GroupNorm partials (query i2i_igemm_gn_parts first)");
     const bool halo_forced = p.tile >= 10 && p.tile <= 19;
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
@@ -310,4 +313,12 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
         case I2I_F16: return launch_t<_Float16>(p, s);
         default: return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     }
+}
+
+extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int groups) {
+    if (!pp) return 0;
+    i2i_igemm_params p = *pp;
+    if (p.zcount < 1) p.zcount = 1;
+    if (p.tile != 0 && !(p.tile >= 10 && p.tile <= 19)) return 0;
+    return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
 }

@@ -99,18 +99,30 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
     const int ct = p.c0 + p.c1, cpg = ct / p.groups;
     float* mean = (float*)i2i_smem;
     float* rstd = mean + p.groups;
-    for (int g = tid; g < p.groups; g += 256) {
+    float* red = rstd + p.groups;                 // [nsl][groups][2] slice partials
+    // nsl slices of the part range per group (conv epilogues hand over thousands of parts); the slices are
+    // combined in a fixed order afterwards, so the result does not depend on scheduling
+    const int nsl = p.groups <= 256 ? (256 / p.groups) : 1;
+    const int g = tid % p.groups, sl = tid / p.groups;
+    if (sl < nsl) {
         float S = 0.f, Q = 0.f;
-        for (int part = 0; part < p.nparts; ++part) {
+        for (int part = sl; part < p.nparts; part += nsl) {
             const float* in = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g) * 2;
             S += in[0];
             Q += in[1];
         }
+        red[(sl * p.groups + g) * 2 + 0] = S;
+        red[(sl * p.groups + g) * 2 + 1] = Q;
+    }
+    __syncthreads();
+    for (int gg = tid; gg < p.groups; gg += 256) {
+        float S = 0.f, Q = 0.f;
+        for (int k = 0; k < nsl; ++k) { S += red[(k * p.groups + gg) * 2]; Q += red[(k * p.groups + gg) * 2 + 1]; }
         const float inv = 1.0f / ((float)cpg * (float)p.hw);
         const float mu = S * inv;
         const float var = fmaxf(Q * inv - mu * mu, 0.f);
-        mean[g] = mu;
-        rstd[g] = rsqrtf(var + p.eps);
+        mean[gg] = mu;
+        rstd[gg] = rsqrtf(var + p.eps);
     }
     __syncthreads();
     for (int c = tid; c < ct; c += 256) {
@@ -223,17 +235,19 @@ __global__ __launch_bounds__(256) void softmax_kernel(const i2i_softmax_params p
 template <typename T>
 int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
     const int ct = p.c0 + p.c1;
-    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3((unsigned)p.nparts, (unsigned)p.nimg), dim3(256), (size_t)ct * 8, s, p);
-    int rc = i2i::check_launch("gn_partial");
-    if (rc) return rc;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg), dim3(256), (size_t)p.groups * 8, s, p);
+    if (!p.finalize_only) {
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3((unsigned)p.nparts, (unsigned)p.nimg), dim3(256), (size_t)ct * 8, s, p);
+        const int rc = i2i::check_launch("gn_partial");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg), dim3(256), (size_t)p.groups * 8 + (size_t)(p.groups <= 256 ? 256 / p.groups : 1) * p.groups * 8, s, p);
     return i2i::check_launch("gn_finalize");
 }
 
 }  // namespace
 
 extern "C" int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream) {
-    if (!p || !p->x0 || !p->partial || !p->ss || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: null pointer");
+    if (!p || (!p->x0 && !p->finalize_only) || !p->partial || !p->ss || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: null pointer");
     const int ct = p->c0 + p->c1;
     if (p->c0 % 8 || p->c1 % 8 || p->ld0 % 8 || (p->x1 && p->ld1 % 8)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: channels must be multiples of 8");
     if (ct % p->groups || ct > GN_JMAX * 64 * 8 || p->groups > 256 || p->nparts < 1) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: bad geometry (ct=%d groups=%d)", ct, p->groups);

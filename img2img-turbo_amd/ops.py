@@ -67,9 +67,10 @@ def bgemm(a, b, out, *, M, N, Kdim, lda, ldb, ldc, batch, heads, a_bs, b_bs, c_b
 
 
 def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=None, c0=None, c1=0,
-             ld0=None, ld1=None):
+             ld0=None, ld1=None, finalize_only=0):
     p = K.GnStatsParams()
     p.x0, p.x1 = ptr(x0), ptr(x1)
+    p.finalize_only = finalize_only
     p.c0 = x0.shape[-1] if c0 is None else c0
     p.c1 = c1
     p.ld0 = ld0 if ld0 is not None else x0.shape[-1]

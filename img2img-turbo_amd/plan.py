@@ -27,6 +27,7 @@ class Act:
     h: int
     w: int
     c: int
+    producer: object = None     # IgemmParams of the op that wrote this tensor (GroupNorm partial-sum fusion)
 
     @property
     def hw(self):
@@ -71,7 +72,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         if (H // 8) % 8 or (W // 8) % 8:
             raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
@@ -81,6 +82,7 @@ class ForwardPlan:
         self.dt = O.DT[dtype]
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
+        self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
         self.dma_small = dma_small   # non-halo GN convs: materialise GN and use the LDS-DMA igemm (+ split-K)
         self.ua, self.va = weights.unet_arch, weights.vae_arch
         vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
@@ -99,6 +101,7 @@ class ForwardPlan:
         self._gn_part_elems = 0
         self._gn_ss_elems = 0
         self._pending_gn = []
+        self._keep = []         # tensors referenced by the program that are not owned by the pool
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -136,6 +139,8 @@ class ForwardPlan:
         for p, which in self._pending_gn:   # patch pointers now that the scratch exists
             if which == "stats":
                 p.partial, p.ss = self.gn_partial.data_ptr(), self.gn_ss.data_ptr()
+            elif which == "stats_ss":
+                p.ss = self.gn_ss.data_ptr()
             elif which == "igemm":
                 p.gn_ss = self.gn_ss.data_ptr()
             else:
@@ -144,6 +149,22 @@ class ForwardPlan:
     def gn_stats(self, pk, norm_name, x: Act, groups, eps, x1: Optional[Act] = None, label=""):
         gamma, beta = pk.norm(norm_name)
         ct = x.c + (x1.c if x1 else 0)
+        # Fused statistics: when the tensor was written by a conv whose epilogue can emit GroupNorm partial sums
+        # (i2i_igemm_gn_parts > 0), the streaming re-read of the tensor disappears; only the tiny finalize runs.
+        if self.fuse_gn_stats and x1 is None and x.producer is not None and not x.producer.gn_part:
+            parts = self.lib.igemm_gn_parts(x.producer, self.dt, groups)
+            if parts > 0:
+                # dedicated slab (not pooled): it is written by an op recorded EARLIER than this point, so a pooled
+                # buffer could have been lent to an op in between
+                part = torch.empty(x.n * parts * groups * 2, dtype=torch.float32, device=self.device)
+                self._keep.append(part)
+                x.producer.gn_part, x.producer.gn_part_groups = part.data_ptr(), groups
+                self._gn_scratch(x.n, ct, 1, groups)
+                op = O.gn_stats(None, gamma, beta, part, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=parts,
+                                c0=x.c, ld0=x.c, finalize_only=1)
+                self._pending_gn.append((op[1], "stats_ss"))
+                self._add(op, (label or norm_name) + ".finalize")
+                return
         nparts = int(min(256, max(1, (x.hw * ct) // 65536)))
         self._gn_scratch(x.n, ct, nparts, groups)
         op = O.gn_stats(x.t, gamma, beta, None, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=nparts,
@@ -213,6 +234,7 @@ class ForwardPlan:
                     splitk=splitk, ws=ws)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
+        out.producer = op[1]
         if fused:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch

@@ -86,6 +86,10 @@ typedef struct {
                                   1-5 register-staged igemm, 10-19 halo conv3x3, 20-25 LDS-DMA igemm */
     int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
     void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */
+    float* gn_part;            /* optional: GroupNorm partial sums of the OUTPUT tensor (as stored), written by the
+                                  epilogue as [nimg][parts][gn_part_groups][2] = (sum, sum of squares) with
+                                  parts = i2i_igemm_gn_parts(); finished by I2I_OP_GN_STATS with finalize_only */
+    int32_t gn_part_groups;
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.
@@ -97,6 +101,7 @@ typedef struct {
     const float* gamma; const float* beta;    /* [c0+c1] fp32 */
     float* partial; int32_t nparts;
     float* ss;                                /* out [nimg][c0+c1][2] */
+    int32_t finalize_only;                    /* 1: `partial` was produced by a conv epilogue (gn_part); x0 unused */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its
@@ -178,6 +183,9 @@ size_t i2i_sizeof_op(void);               /* sanity check for FFI struct layout 
 
 /* ---- single-op entry points (each = one or two kernel launches on `stream`) ---- */
 int i2i_igemm(const i2i_igemm_params* p, int dtype, void* stream);
+/* Number of partial-sum slots per image this op would write through gn_part (its spatial tile count), or 0 if
+ * the kernel that will run it cannot produce GroupNorm partials (planner query; launches nothing). */
+int i2i_igemm_gn_parts(const i2i_igemm_params* p, int dtype, int groups);
 int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);
 int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream);
 int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream);
