@@ -53,12 +53,13 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--out", default="gpurun_out/bench_ops.json")
     ap.add_argument("--only", default="", help="substring filter on shape names")
+    ap.add_argument("--lib", default=None, help="alternate build of the library (ablation experiments)")
     ap.add_argument("--splitk", default="0", help="comma list of split-K factors to try (LDS-DMA igemm)")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = 157.3 if a.dtype == "f32" else 2500.0
-    lib = K.default_library()
+    lib = K.Library(a.lib) if a.lib else K.default_library()
     dev = "cuda"
     res = []
     for name, cin, cout, H, W, ks, stride, ups, gn in SHAPES:

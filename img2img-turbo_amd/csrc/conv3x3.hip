@@ -130,12 +130,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         if (wave == 0 && lane < CK / 2)
             glds16(p.gn_ss + ((int64_t)img * cin + slab * CK) * 2 + lane * 4, Ss);
     };
-    auto halo_load = [&](int slab, int j) __attribute__((always_inline)) {
+    // One 16-byte load per call, ALWAYS and branch-free (padding lanes read pixel 0 of the image and are zeroed when
+    // the halo is stored): the counted vmcnt waits rely on every wave issuing the same number of VMEM operations
+    // per window.  `hidden`: the load is invisible to hipcc's waitcnt bookkeeping (see gload16_uncounted).
+    auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
         const int ci = slab * CK;                                       // wave-uniform source select
         const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
         const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
-        if (hpix[j] == ~0u) rh[j] = zero_chunk<T>();
-        else rh[j] = *(const chunk_t*)(base + (hpix[j] * ldb + (unsigned)kc * 16u));
+        const unsigned pix = (hpix[j] == ~0u) ? 0u : hpix[j];
+        const unsigned voff = pix * ldb + (unsigned)kc * 16u;
+        if (hidden) gload16_uncounted(rh[j], base, voff);
+        else rh[j] = *(const chunk_t*)(base + voff);
     };
     auto halo_store_all = [&]() __attribute__((always_inline)) {
         float ssr[2 * EPC];
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         for (int j = 0; j < HPT; ++j) {
             const int hp = (tid >> 3) + j * (NT / 8);
             if (hp < HALO) {
-                chunk_t c = rh[j];
+                chunk_t c = (hpix[j] != ~0u) ? rh[j] : zero_chunk<T>();
                 if (has_gn && hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
                     float v[EPC];
 #pragma unroll
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     b_dma(0, 2, 2);
     if (has_gn) ss_dma(0);
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) halo_load(0, j);
+    for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
     wait_vmcnt<0>();
     lds_barrier();
     halo_store_all();
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         for (int m = 0; m < 8; ++m) x_off[m] = u * 128 + ((lq ^ lds_swz2(u + m)) << 4);
     }
     // weight fragment row = wn*WTN + j*16 + lr (swizzle independent of j): base of buffer 0, k-group 0
-    const int w_off = lds_chunk_off2(wn * WTN + lr, lq) + HALO * 128;
+    constexpr bool PERM = (EPC == 8) && (FN % 2 == 0);    // 16-bit outputs: weight rows permuted for 16-byte stores
+    const int w_off = lds_chunk_off2(wn * WTN + (PERM ? frag_row_perm(lr) : lr), lq) + HALO * 128;
 
     // ---- the step pipeline.  A step = one (slab, tap) = 2 k-groups x FM tile rows = 2*FM "row groups" of FN
     // MFMAs each.  Fragment reads run AHEAD of the MFMAs that use them, across k-groups and across the
@@ -267,27 +273,32 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         }
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, gc, more); });
         __builtin_amdgcn_sched_barrier(0);
-        // -- P_s: publish B[s+1].  Outstanding VMEM ops allowed = the batch issued after P_{s-1}
-        //    (DMA of B[s+2] + the halo loads of tap-1), if that batch exists; tap 0 follows a full drain.
-        if constexpr (tap == 0) {
-            wait_vmcnt<0>();
-        } else {
-            if (next_slab) wait_vmcnt<DMA_OPS + nh(tap - 1)>();
-            else if (tap + 2 < 9) wait_vmcnt<DMA_OPS>();
-            else wait_vmcnt<0>();
+        // -- P_s: publish B[s+1].  Outstanding VMEM ops allowed = the window issued after P_{s-1}: the halo loads of
+        //    tap-1 (always issued) and, if it exists, the DMA batch of B[s+2].  At tap 0 the previous window is
+        //    tap 8 of the previous slab, whose halo loads the hand-over already waited for.
+        {
+            constexpr int nhp = (tap == 0) ? 0 : nh(tap - 1);
+            if (tap + 2 < 9 || next_slab) wait_vmcnt<DMA_OPS + nhp>();
+            else wait_vmcnt<nhp>();
         }
         lds_barrier();
-        // -- window after P_s: DMA of B[s+3] into the buffer just released, next slab's halo into registers
+        // -- window after P_s: next slab's halo into registers (uncounted loads; from the current slab again when
+        //    there is no next one, so the count per window never changes), then the DMA of B[s+3] into the buffer
+        //    just released.  Halo first: the hand-over then waits with vmcnt(DMA_OPS) and leaves the DMA in flight.
+        {
+            const int hs = next_slab ? slab + 1 : slab;
+            if constexpr (tap < HPT) halo_load(hs, tap, true);
+            if constexpr (tap + 9 < HPT) halo_load(hs, tap + 9, true);
+        }
         if (tap + 3 < 9) b_dma(slab, tap + 3, tap % 3);
         else if (next_slab) b_dma(slab + 1, tap + 3 - 9, tap % 3);
-        if (next_slab) {
-            if constexpr (tap < HPT) halo_load(slab + 1, tap);
-            if constexpr (tap + 9 < HPT) halo_load(slab + 1, tap + 9);
-        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
         __builtin_amdgcn_sched_barrier(0);
         if (tap == 8 && next_slab) {                      // halo hand-over: everyone is done reading Hs
+            wait_vmcnt<DMA_OPS>();                        // my halo loads have landed (the newer DMA batch stays in flight)
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
             lds_barrier();
             halo_store_all();
             lds_barrier();
@@ -309,59 +320,124 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         step(slab, next_slab, ic<7>{});
         step(slab, next_slab, ic<8>{});
     }
+    // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
+    // destination registers -- hipcc does not know those registers have a write in flight.
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
 
-    // ---- epilogue: lane holds channels n = .. + 4*lq + (0..3) of pixel (oy, tx0 + lr): alpha, bias, residual,
-    // one 8-byte (fp32: 16-byte) store per fragment
+    // ---- epilogue: alpha, bias, residual, store, GroupNorm partial sums of what was stored.
+    // Lane (lr, lq) holds pixel (oy, tx0 + lr).  16-bit outputs with an even fragment count take the wide path:
+    // fragment pairs are half-exchanged (widen_pair) so every lane stores 16 bytes = 8 consecutive channels;
+    // otherwise 4 consecutive channels (8 bytes, fp32 16) of channel quad `lqc` per fragment.
     const T* __restrict__ res = (const T*)p.res;
     const int ox = tx0 + lr;
     const bool do_stats = p.gn_part != nullptr;      // GroupNorm partial sums of the stored output (next layer's norm)
-    float gs[FN], gq[FN];
+    float gs[FN], gq[FN];                            // per 4-channel quad this lane accumulates (wide: 2 per fragment pair)
+    int gquad[FN];                                   // its quad index inside the wave's channel span (channel / 4)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    for (int j = 0; j < FN; ++j) { gs[j] = 0.f; gq[j] = 0.f; gquad[j] = 0; }
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0);
+    if (wide) {
+        if constexpr (PERM) {
+            // residual chunks first, all of them in flight together (the stores below may alias them as far as
+            // the compiler knows, so it would otherwise serialise load -> wait -> store per fragment)
+            chunk_t rres[FM][FN / 2];
+            if (res) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + lq * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) {
+                for (int jp = 0; jp < FN / 2; ++jp) {
+                    const int n = n0 + wn * WTN + (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int oy = ty0 + wm * FM + i;
-            if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
-            const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r];
-            if (n + 3 < p.N) {
-                if (res) {
-                    typedef T tx4 __attribute__((ext_vector_type(4)));
-                    const tx4 rv = *(const tx4*)(res + m * p.ldr + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rv[r]);
-                }
-                if (p.out_f32) {
-                    *(f32x4*)((float*)p.c + m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    typedef T tx4 __attribute__((ext_vector_type(4)));
-                    tx4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-                    *(tx4*)((T*)p.c + m * p.ldc + n) = o;
-                    if (do_stats) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float f = to_f32<T>(o[r]); gs[j] += f; gq[j] += f * f; }
+                    for (int i = 0; i < FM; ++i) {
+                        const int oy = ty0 + wm * FM + i;
+                        const bool ok = ox < p.wo && oy < p.ho && n < p.N;
+                        const int64_t m = ((int64_t)img * p.ho + (ok ? oy : ty0)) * p.wo + (ok ? ox : tx0);
+                        rres[i][jp] = *(const chunk_t*)(res + m * p.ldr + (ok ? n : 0));
                     }
                 }
-            } else {
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r < p.N) {
-                        float t = v[r];
-                        if (res) t += to_f32<T>(res[m * p.ldr + n + r]);
-                        if (p.out_f32) ((float*)p.c)[m * p.ldc + n + r] = t;
-                        else ((T*)p.c)[m * p.ldc + n + r] = from_f32<T>(t);
+            for (int jp = 0; jp < FN / 2; ++jp) {
+                const int cw = (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;     // channel inside the wave's span
+                const int n = n0 + wn * WTN + cw;
+                gquad[2 * jp] = cw >> 2; gquad[2 * jp + 1] = (cw >> 2) + 1;
+                float bv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    float v[8];
+                    widen_pair(acc[i][2 * jp], acc[i][2 * jp + 1], v);        // wave-wide: before any lane drops out
+                    const int oy = ty0 + wm * FM + i;
+                    if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
+                    const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r];
+                    if (res) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][jp][r]);
+                    }
+                    chunk_t o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                    *(chunk_t*)((T*)p.c + m * p.ldc + n) = o;
+                    if (do_stats) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float f = to_f32<T>(o[r]);
+                            gs[2 * jp + (r >> 2)] += f; gq[2 * jp + (r >> 2)] += f * f;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + lqc * 4;
+            gquad[j] = j * 4 + lqc;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias_mode == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int oy = ty0 + wm * FM + i;
+                if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
+                const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r];
+                if (n + 3 < p.N) {
+                    if (res) {
+                        const tx4 rv = *(const tx4*)(res + m * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rv[r]);
+                    }
+                    if (p.out_f32) {
+                        *(f32x4*)((float*)p.c + m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        tx4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                        *(tx4*)((T*)p.c + m * p.ldc + n) = o;
+                        if (do_stats) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float f = to_f32<T>(o[r]); gs[j] += f; gq[j] += f * f; }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (n + r < p.N) {
+                            float t = v[r];
+                            if (res) t += to_f32<T>(res[m * p.ldr + n + r]);
+                            if (p.out_f32) ((float*)p.c)[m * p.ldc + n + r] = t;
+                            else ((T*)p.c)[m * p.ldc + n + r] = from_f32<T>(t);
+                        }
                     }
                 }
             }
@@ -380,8 +456,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         if (lr == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                st[((wave * FN + j) * 4 + lq) * 2 + 0] = gs[j];
-                st[((wave * FN + j) * 4 + lq) * 2 + 1] = gq[j];
+                st[(wave * FN * 4 + gquad[j]) * 2 + 0] = gs[j];
+                st[(wave * FN * 4 + gquad[j]) * 2 + 1] = gq[j];
             }
         }
         lds_barrier();

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 
     // ---- per-lane fragment offsets: "register + immediate" for every read (rows are 16-aligned here) ----
     const int x_off = lds_chunk_off2(wm * WTM + lr, lq);                  // A rows (m):  + i*2048, ^64 for k-group 1
-    const int w_off = BM * 128 + lds_chunk_off2(wn * WTN + lr, lq);       // B rows (n):  + j*2048
+    constexpr bool PERM = (EPC == 8) && (FN % 2 == 0);    // 16-bit: weight rows permuted for 16-byte stores (i2i_dev.h)
+    const int w_off = BM * 128 + lds_chunk_off2(wn * WTN + (PERM ? frag_row_perm(lr) : lr), lq);   // B rows (n): + j*2048
     // Two fragment register sets: {xa, w0} = k-group 0 of a stage, {xb, w1} = k-group 1.  A stage is READ
     // only between the barrier that publishes it (P_{s-1}) and its own barrier P_s: phase A of step s
     // (k-group 0 MFMAs) loads {xb, w1} of stage s; phase B (k-group 1 MFMAs, after P_s) loads {xa, w0} of
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
         }
     }
 
-    // ---- epilogue: lane owns n = nb + 4*lq + (0..3) of row m = mb + lr ----
+    // ---- epilogue: lane owns row m = mb + lr and, per fragment, channel quad lqc (n = nb + 4*lqc + 0..3); 16-bit
+    // outputs with an even fragment count are widened to 8 consecutive n per lane (widen_pair, 16-byte stores)
+    const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
     const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
     const int64_t r_off = (int64_t)zb * p.r_bs_b + (int64_t)zh * p.r_bs_h;
     typedef T tx4 __attribute__((ext_vector_type(4)));
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             const int m = m0 + wm * WTM + i * 16 + lr;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + lq * 4;
+                const int n = n0 + wn * WTN + j * 16 + lqc * 4;
                 if (m < p.M && n < p.N) {
                     if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4*)(ws + (int64_t)m * p.N + n) = acc[i][j];
                     else
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
         if constexpr (FN >= 2) {
 #pragma unroll
             for (int j = 0; j + 1 < FN; j += 2) {
-                const int nA = n0 + wn * WTN + j * 16 + lq * 4;           // packed column of the 4 values
+                const int nA = n0 + wn * WTN + j * 16 + lqc * 4;          // packed column of the 4 values
                 const int nG = nA + 16;
-                const int no = (n0 + wn * WTN + j * 16) / 2 + lq * 4;     // output column of the 4 results
+                const int no = (n0 + wn * WTN + j * 16) / 2 + lqc * 4;    // output column of the 4 results
                 if (nG >= p.N) continue;
                 float bA[4] = {0.f, 0.f, 0.f, 0.f}, bG[4] = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) {
@@ -282,9 +285,55 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
         }
         return;
     }
+    const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0) &&
+                      (((c_off | r_off) & 7) == 0) && (((uintptr_t)p.res & 15) == 0);
+    if (wide) {
+        if constexpr (PERM) {
+            // residual chunks first, all in flight together (the compiler cannot hoist them over the stores itself)
+            chunk_t rres[FM][FN / 2];
+            if (res) {
+#pragma unroll
+                for (int jp = 0; jp < FN / 2; ++jp) {
+                    const int n = n0 + wn * WTN + (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m = m0 + wm * WTM + i * 16 + lr;
+                        const bool ok = m < p.M && n < p.N;
+                        rres[i][jp] = *(const chunk_t*)(res + (int64_t)(ok ? m : m0) * p.ldr + (ok ? n : 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int jp = 0; jp < FN / 2; ++jp) {
+                const int n = n0 + wn * WTN + (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;
+                float bv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    float v[8];
+                    widen_pair(acc[i][2 * jp], acc[i][2 * jp + 1], v);        // wave-wide: before any lane drops out
+                    const int m = m0 + wm * WTM + i * 16 + lr;
+                    if (m >= p.M || n >= p.N) continue;
+                    const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r] + bm;
+                    if (res) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][jp][r]);
+                    }
+                    chunk_t o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                    *(chunk_t*)((T*)p.c + c_off + (int64_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + lq * 4;
+        const int n = n0 + wn * WTN + j * 16 + lqc * 4;
         if (n >= p.N) continue;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias_mode == 1) {

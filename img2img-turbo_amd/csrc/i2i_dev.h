@@ -94,11 +94,55 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #endif
+// A 16-byte global load hipcc does NOT count (cdna_hip_programming.md 5.7 form (ii)): beside an LDS-DMA pipeline
+// the compiler drains vmcnt(0) before/after every ordinary VGPR load it can see, which would serialise the DMA
+// ring.  The caller owns the completion: a counted wait_vmcnt<N>() followed by reg_fence() on every destination
+// before its first use; between load and fence the destination must not be touched (keep the load unconditional,
+// no phi).  sbase must be provably wave-uniform (SGPR pair), voff a 32-bit byte offset.
+#ifdef I2I_EMU
+template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) { dst = *(const C*)(sbase + voff); }
+template <typename C> __device__ __forceinline__ void reg_fence(C&) {}
+#else
+template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) {
+    // s_nop 4: hipcc pads nothing inside an asm string, and the SGPR base / VGPR offset are usually written by the
+    // SALU / VALU instructions just ahead (SALU-write -> VMEM-read of an SGPR needs 5 wait states)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <typename C> __device__ __forceinline__ void reg_fence(C& x) { asm volatile("" : "+v"(x)); }
+#endif
 // workgroup barrier that orders LDS traffic only (the caller places the vmcnt wait it needs)
 __device__ __forceinline__ void lds_barrier() {
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     wait_lgkm0();
+}
+
+// ---- 16-byte epilogue stores for 16-bit outputs (cdna_hip_programming.md T21).  With the MFMA operands swapped
+// a lane of quad lq owns 4 consecutive channels of one pixel per 16-channel fragment (an 8-byte store).  The
+// weight rows of every fragment are loaded PERMUTED (frag_row_perm: quads 1 and 2 exchanged) so that lane
+// quads lq and lq+2 -- which v_permlane32_swap can exchange -- own ADJACENT channel quads; one half exchange
+// per accumulator register over a fragment pair (j, j+1) then leaves 8 consecutive channels in every lane:
+// lanes 0-31 finish fragment j, lanes 32-63 fragment j+1, channel base (lq & 1) * 8.
+__device__ __forceinline__ int frag_row_perm(int lr) { return (lr & 3) | ((lr & 4) << 1) | ((lr & 8) >> 1); }
+__device__ __forceinline__ int frag_quad_of_lane(int lq) { return ((lq & 1) << 1) | (lq >> 1); }   // channel quad a lane quad owns
+#ifdef I2I_EMU
+__device__ __forceinline__ void half_swap(float& a, float& b) { emu::permlane32_swap(a, b); }
+#else
+__device__ __forceinline__ void half_swap(float& a, float& b) {     // a[lanes 32-63] <-> b[lanes 0-31]
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+#endif
+// v[0..7] = the 8 consecutive channels this lane owns after the exchange of fragments a (j) and b (j+1)
+__device__ __forceinline__ void widen_pair(f32x4 a, f32x4 b, float v[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x = a[r], y = b[r];
+        half_swap(x, y);
+        v[r] = x;
+        v[4 + r] = y;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

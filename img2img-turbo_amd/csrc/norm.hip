@@ -94,39 +94,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const i2i_gn_stats_para
     }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_params p) {
-    const int tid = threadIdx.x, img = blockIdx.x;
+// grid = (nimg, groups / gpb): a block finishes gpb groups of one image.  Each group's part range is cut into
+// 256 / gpb slices (conv epilogues hand over thousands of parts) that are combined in a fixed order afterwards,
+// so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_params p, int gpb) {
+    const int tid = threadIdx.x, img = blockIdx.x, g0 = blockIdx.y * gpb;
     const int ct = p.c0 + p.c1, cpg = ct / p.groups;
-    float* mean = (float*)i2i_smem;
-    float* rstd = mean + p.groups;
-    float* red = rstd + p.groups;                 // [nsl][groups][2] slice partials
-    // nsl slices of the part range per group (conv epilogues hand over thousands of parts); the slices are
-    // combined in a fixed order afterwards, so the result does not depend on scheduling
-    const int nsl = p.groups <= 256 ? (256 / p.groups) : 1;
-    const int g = tid % p.groups, sl = tid / p.groups;
+    float* mean = (float*)i2i_smem;               // [gpb]
+    float* rstd = mean + gpb;                     // [gpb]
+    float* red = rstd + gpb;                      // [nsl][gpb][2] slice partials
+    const int nsl = 256 / gpb;
+    const int gl = tid % gpb, sl = tid / gpb;
     if (sl < nsl) {
         float S = 0.f, Q = 0.f;
         for (int part = sl; part < p.nparts; part += nsl) {
-            const float* in = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g) * 2;
+            const float* in = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g0 + gl) * 2;
             S += in[0];
             Q += in[1];
         }
-        red[(sl * p.groups + g) * 2 + 0] = S;
-        red[(sl * p.groups + g) * 2 + 1] = Q;
+        red[(sl * gpb + gl) * 2 + 0] = S;
+        red[(sl * gpb + gl) * 2 + 1] = Q;
     }
     __syncthreads();
-    for (int gg = tid; gg < p.groups; gg += 256) {
+    if (tid < gpb) {
         float S = 0.f, Q = 0.f;
-        for (int k = 0; k < nsl; ++k) { S += red[(k * p.groups + gg) * 2]; Q += red[(k * p.groups + gg) * 2 + 1]; }
+        for (int k = 0; k < nsl; ++k) { S += red[(k * gpb + tid) * 2]; Q += red[(k * gpb + tid) * 2 + 1]; }
         const float inv = 1.0f / ((float)cpg * (float)p.hw);
         const float mu = S * inv;
         const float var = fmaxf(Q * inv - mu * mu, 0.f);
-        mean[gg] = mu;
-        rstd[gg] = rsqrtf(var + p.eps);
+        mean[tid] = mu;
+        rstd[tid] = rsqrtf(var + p.eps);
     }
     __syncthreads();
-    for (int c = tid; c < ct; c += 256) {
-        const int g = c / cpg;
+    for (int c = g0 * cpg + tid; c < (g0 + gpb) * cpg; c += 256) {
+        const int g = c / cpg - g0;
         const float sc = rstd[g] * p.gamma[c];
         float* o = p.ss + ((int64_t)img * ct + c) * 2;
         o[0] = sc;
@@ -240,7 +241,10 @@ int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
         const int rc = i2i::check_launch("gn_partial");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg), dim3(256), (size_t)p.groups * 8 + (size_t)(p.groups <= 256 ? 256 / p.groups : 1) * p.groups * 8, s, p);
+    int gpb = p.groups;                            // groups per block: 8 when that divides, else all (<= 256)
+    if (p.groups % 8 == 0) gpb = 8;
+    else if (p.groups % 4 == 0) gpb = 4;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256), (size_t)gpb * 8 + (size_t)(256 / gpb) * gpb * 8, s, p, gpb);
     return i2i::check_launch("gn_finalize");
 }
 

@@ -97,6 +97,21 @@ template <class T> static inline T __shfl_down(T v, int d, int = 64) { return em
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl_generic(v, 0, 1); }
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 namespace emu {
+// v_permlane32_swap_b32 a, b: lanes 32-63 of a exchange with lanes 0-31 of b.
+static inline void permlane32_swap(float& a, float& b) {
+    struct In { float a, b; } in = {a, b};
+    float out[2];
+    wave_collective(&in, sizeof(in), out, sizeof(out),
+        [](const char* is, char* os, void*) {
+            for (int l = 0; l < 64; ++l) {
+                const In* me = (const In*)(is + l * kMaxIn);
+                float* o = (float*)(os + l * kMaxOut);
+                if (l < 32) { o[0] = me->a; o[1] = ((const In*)(is + (l + 32) * kMaxIn))->a; }
+                else        { o[0] = ((const In*)(is + (l - 32) * kMaxIn))->b; o[1] = me->b; }
+            }
+        }, nullptr);
+    a = out[0]; b = out[1];
+}
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; executed synchronously here.
 static inline void global_load_lds16(const void* g, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + 16 * lane_id(), g, 16);

@@ -294,3 +294,40 @@ def check_latent_ops(lib, device, dtype, *, n=2, h=4, w=6, seed=0, r=0.4):
     err = rel_err(y.cpu()[..., :lat], ref)
     assert err < max(TOL[dtype], 1e-4) and (y.cpu().float()[..., lat:] == 0).all()
     return err
+
+
+def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, groups=8, tile=10, res=True, seed=0):
+    """3x3 conv whose epilogue emits the GroupNorm partial sums of its OUTPUT (gn_part), finished by
+    gn_stats(finalize_only): the (scale, shift) pairs must match statistics taken from the stored tensor."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(n, cout, h, w, generator=g) if res else None
+    gamma = 1 + 0.1 * torch.randn(cout, generator=g)
+    beta = 0.1 * torch.randn(cout, generator=g)
+    x0 = nhwc(x, dtype).to(device)
+    wp = pack_conv_weight(wt, dtype).to(device)
+    out = torch.full((n, h, w, cout), float("nan"), dtype=dtype, device=device)
+    rd = nhwc(r, dtype).to(device) if res else None
+    bdev = b.to(device)      # keep alive: the op only holds raw pointers
+    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=h, wo=w, ks=3, stride=1, pad=1, N=cout, bias=bdev, res=rd, tile=tile)
+    parts = lib.igemm_gn_parts(p, O.DT[dtype], groups)
+    assert parts > 0, "kernel declined GroupNorm partials"
+    part = torch.full((n * parts * groups * 2,), float("nan"), device=device)
+    p.gn_part, p.gn_part_groups = part.data_ptr(), groups
+    ss = torch.full((n, cout, 2), float("nan"), device=device)
+    gd, bd = gamma.to(device), beta.to(device)
+    op2, p2 = O.gn_stats(None, gd, bd, part, ss, nimg=n, hw=h * w, groups=groups, eps=1e-5, nparts=parts, c0=cout, ld0=cout, finalize_only=1)
+    prog = K.Program()
+    prog.add(opcode, O.DT[dtype], p)
+    prog.add(op2, O.DT[dtype], p2)
+    prog.freeze()
+    lib.run(prog, torch.cuda.current_stream().cuda_stream if device != "cpu" else 0)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    stored = out.cpu().float().permute(0, 3, 1, 2)
+    ref = gn_scale_shift(stored, groups, gamma, beta, 1e-5)
+    err = rel_err(ss.cpu(), ref)
+    assert err < 2e-4, f"fused gn stats rel err {err}"
+    return err

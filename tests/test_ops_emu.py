@@ -164,3 +164,10 @@ def test_dma_igemm_splitk(emu_lib, splitk):
     """Weight-streaming shape in miniature: few rows, long K (3x3 over 4 slabs = 36 steps), split over grid z."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=72, h=4, w=4, res=True, tile=23, splitk=splitk)
     oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=96, cout=40, h=4, w=4, tile=24, splitk=splitk)
+
+
+@pytest.mark.parametrize("cfg,dtype", [(13, torch.bfloat16), (17, torch.float32), (12, torch.bfloat16), (14, torch.float16), (15, torch.bfloat16)])
+def test_conv_epilogue_groupnorm_partials(emu_lib, cfg, dtype):
+    """gn_part: per-tile partial sums from the conv epilogue + finalize_only == statistics of the stored tensor."""
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=cfg)      # ragged tiles
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=1, cin=64, cout=192, h=16, w=16, groups=12, tile=cfg, res=False)  # cpg 16, 2 n-tiles

@@ -106,3 +106,11 @@ def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
     oc.check_bgemm(gpu_lib, "cuda", dtype, out_f32=0, tile=22, M=130, N=64, Kd=128)
     for sk in (2, 6, 9):
         oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=512, cout=200, h=8, w=8, res=True, tile=23, splitk=sk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [12, 13, 17, 18])
+def test_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
+    for dtype in (torch.bfloat16, torch.float32):
+        oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=72, w=40, groups=32, tile=cfg)
+        oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=64, cout=512, h=32, w=32, groups=32, tile=cfg, res=False)
