@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int TW = 16, HW2 = TW + 2;
+constexpr int TW = 16;
 template <int V> struct ic { static constexpr int value = V; };   // compile-time int passed through generic lambdas
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {   // f(ic<0>{}) ... f(ic<N-1>{})
     if constexpr (N > 0) {
@@ -35,13 +35,19 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {   
     }
 }
 
-// PD = pixel-fragment prefetch distance in row groups (2 or 3); MINW = min waves per SIMD for the register allocator
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
+// PD = pixel-fragment prefetch distance in row groups (2 or 3); MINW = min waves per SIMD for the register allocator.
+// SUBPIX: sub-pixel form of "nearest-2x upsample then 3x3 conv" (diffusers Upsample2D): output pixel (2y+a, 2x+b)
+// only ever sees a 2x2 neighbourhood of the SOURCE plane, so each output parity (a,b) is a 2x2 convolution of
+// the source with the tap weights pre-summed (packer.subpixel_weights) -- 4/9 of the MFMA work, no index map.
+// A workgroup then owns TH x 16 SOURCE positions of one parity: halo (TH+1) x 17, 4 taps per slab, 2-deep weight
+// ring (4 % 3 != 0), outputs scattered to (2y+a, 2x+b).
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i2i_igemm_params p) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int CK = 8 * EPC;                      // channels per slab: 64 (16-bit) / 32 (f32)
-    constexpr int HALO = (TH + 2) * HW2;
+    constexpr int KS = SUBPIX ? 2 : 3, NTAPS = KS * KS, RING = SUBPIX ? 2 : 3;
+    constexpr int HW2 = TW + KS - 1, HALO = (TH + KS - 1) * HW2;
     static_assert(TH % WM == 0 && BN % (16 * WN) == 0, "");
     constexpr int FM = TH / WM;                      // m-fragments per wave = tile rows per wave
     constexpr int WTN = BN / WN, FN = WTN / 16;
@@ -64,9 +70,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
+    // plane the tiles walk over: the output plane, or the SOURCE plane for the sub-pixel form
+    const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
+    const int tiles_x = (pl_w + TW - 1) / TW, tiles_y = (pl_h + TH - 1) / TH;
     const int ntn = (p.N + BN - 1) / BN;
     const int tn = bid % ntn; bid /= ntn;
+    int pa = 0, pb = 0;                              // output parity (row, column) of this workgroup
+    if (SUBPIX) { pa = (bid >> 1) & 1; pb = bid & 1; bid >>= 2; }
     const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * TH;
     const int img = bid / tiles_y;
@@ -74,14 +84,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 
     const T* __restrict__ a0 = (const T*)p.a0;
     const T* __restrict__ a1 = (const T*)p.a1;
-    const T* __restrict__ bw = (const T*)p.b;
+    const T* __restrict__ bw = (const T*)p.b + (SUBPIX ? (int64_t)(pa * 2 + pb) * p.N * p.ldb : 0);
     const int cin = p.c0 + p.c1;
     const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
     const bool has_gn = p.gn_ss != nullptr;
 
     char* Hs = i2i_smem;                             // [HALO] rows of 128 B (one slab)
-    char* Bs = i2i_smem + HALO * 128;                // [3][BN] rows of 128 B (step s lives in buffer tap % 3)
-    char* Ss = Bs + 3 * BN * 128;                    // [CK][2] fp32 GroupNorm (scale, shift) of the slab in flight
+    char* Bs = i2i_smem + HALO * 128;                // [RING][BN] rows of 128 B (step s lives in buffer tap % RING)
+    char* Ss = Bs + RING * BN * 128;                    // [CK][2] fp32 GroupNorm (scale, shift) of the slab in flight
 
     // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
     // One 32-bit pixel index per chunk (inside image `img`; ~0 = zero padding); the byte offset
@@ -93,9 +103,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         unsigned pix = ~0u;
         if (hp < HALO) {
             const int hy = hp / HW2, hx = hp - hy * HW2;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
-            if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up)
-                pix = (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+            if (SUBPIX) {                                              // source coordinates of halo pixel (hy, hx)
+                const int iy = ty0 + hy + pa - 1, ix = tx0 + hx + pb - 1;
+                if ((unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win) pix = (unsigned)(iy * p.win + ix);
+            } else {
+                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;       // coordinates in the (upsampled) input plane
+                if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up)
+                    pix = (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+            }
         }
         hpix[j] = pix;
     }
@@ -182,9 +197,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     const int nslab = cin / CK;
 
     // ---- prologue: weights of steps 0..2 and the slab's GN constants by DMA, halo of slab 0 through registers ----
-    b_dma(0, 0, 0);
-    b_dma(0, 1, 1);
-    b_dma(0, 2, 2);
+#pragma unroll
+    for (int t = 0; t < RING; ++t) b_dma(0, t, t);
     if (has_gn) ss_dma(0);
 #pragma unroll
     for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
@@ -223,12 +237,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     constexpr int NG = 2 * FM;                       // row groups per step
     static_assert(NG % 4 == 0 && PD >= 1 && PD <= 3, "xq rotation (4 slots) must close over a step");
     auto xf_read = [&](int tapv, int g) __attribute__((always_inline)) -> chunk_t {   // pixel fragment of row group g
-        const int dy = tapv / 3, dx = tapv % 3, kg = g / FM, i = g % FM;
+        const int dy = tapv / KS, dx = tapv % KS, kg = g / FM, i = g % FM;
         const int c = (i + dy) * HW2 + dx;
         return *(const chunk_t*)(i2i_smem + (x_off[c & 7] ^ (kg * 64)) + c * 128);
     };
     auto wf_read = [&](int tapv, int kg, int j) __attribute__((always_inline)) -> chunk_t {
-        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + (tapv % 3) * BN * 128 + j * 2048));
+        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + (tapv % RING) * BN * 128 + j * 2048));
     };
 
     // One row group g of step `tap`: its prefetch reads, then its FN MFMAs (schedule pinned in that order).
@@ -237,10 +251,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         constexpr int kg = g / FM, i = g % FM;
         constexpr int WPG = (FN + FM - 1) / FM;       // weight fragments fetched per row group
         constexpr int j0 = i * WPG, nw = (j0 >= FN) ? 0 : ((j0 + WPG <= FN) ? WPG : FN - j0);
-        constexpr bool xpre = (g + PD < NG) || (tap < 8);
+        constexpr bool xpre = (g + PD < NG) || (tap < NTAPS - 1);
         // pixel fragment PD row groups ahead (next step's first PD at the tail; not across a slab hand-over)
         if constexpr (g + PD < NG) xq[(g + PD) % 4] = xf_read(tap, g + PD);
-        else if constexpr (tap < 8) xq[(g + PD) % 4] = xf_read(tap + 1, g + PD - NG);
+        else if constexpr (tap < NTAPS - 1) xq[(g + PD) % 4] = xf_read(tap + 1, g + PD - NG);
         // weight fragments: k-group 1 of this step during k-group 0, k-group 0 of the next step during k-group 1
 #pragma unroll
         for (int t = 0; t < nw; ++t) {
@@ -260,11 +274,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     //   leaves the batch issued after P_{s+1} in flight -- two full steps of latency cover, never vmcnt(0)
     //   in steady state.
     constexpr int DMA_OPS = (NPIECE % NW == 0) ? BPW : 0;     // DMA instructions every wave issues per batch
-    auto nh = [](int t) constexpr { return (t >= 0 && t < HPT ? 1 : 0) + (t + 9 < HPT && t >= 0 ? 1 : 0); };
+    auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0; j += NTAPS) ++c; return c; };   // halo loads issued in tap t's window
     auto step = [&](int slab, bool next_slab, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
-        const bool more = tap < 8 || next_slab;           // another step follows
-        if (tap == 7 && next_slab && has_gn) ss_dma(slab + 1);   // Ss was last read at the previous hand-over
+        const bool more = tap < NTAPS - 1 || next_slab;   // another step follows
+        if (tap == NTAPS - 2 && next_slab && has_gn) ss_dma(slab + 1);   // Ss was last read at the previous hand-over
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (tap == 0) {                         // first step of a slab: the halo image is new
 #pragma unroll
@@ -276,10 +290,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         // -- P_s: publish B[s+1].  Outstanding VMEM ops allowed = the window issued after P_{s-1}: the halo loads of
         //    tap-1 (always issued) and, if it exists, the DMA batch of B[s+2].  At tap 0 the previous window is
         //    tap 8 of the previous slab, whose halo loads the hand-over already waited for.
-        {
+        if constexpr (RING == 3) {
             constexpr int nhp = (tap == 0) ? 0 : nh(tap - 1);
-            if (tap + 2 < 9 || next_slab) wait_vmcnt<DMA_OPS + nhp>();
+            if (tap + 2 < NTAPS || next_slab) wait_vmcnt<DMA_OPS + nhp>();
             else wait_vmcnt<nhp>();
+        } else {
+            wait_vmcnt<0>();                              // 2-deep ring: B[s+1] is the most recent batch
         }
         lds_barrier();
         // -- window after P_s: next slab's halo into registers (uncounted loads; from the current slab again when
@@ -288,15 +304,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         {
             const int hs = next_slab ? slab + 1 : slab;
             if constexpr (tap < HPT) halo_load(hs, tap, true);
-            if constexpr (tap + 9 < HPT) halo_load(hs, tap + 9, true);
+            if constexpr (tap + NTAPS < HPT) halo_load(hs, tap + NTAPS, true);
+            if constexpr (tap + 2 * NTAPS < HPT) halo_load(hs, tap + 2 * NTAPS, true);
+            static_assert(3 * NTAPS >= HPT, "halo loads do not fit the taps of a slab");
         }
-        if (tap + 3 < 9) b_dma(slab, tap + 3, tap % 3);
-        else if (next_slab) b_dma(slab + 1, tap + 3 - 9, tap % 3);
+        if (tap + RING < NTAPS) b_dma(slab, tap + RING, tap % RING);
+        else if (next_slab) b_dma(slab + 1, tap + RING - NTAPS, tap % RING);
         __builtin_amdgcn_sched_barrier(0);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
         __builtin_amdgcn_sched_barrier(0);
-        if (tap == 8 && next_slab) {                      // halo hand-over: everyone is done reading Hs
-            wait_vmcnt<DMA_OPS>();                        // my halo loads have landed (the newer DMA batch stays in flight)
+        if (tap == NTAPS - 1 && next_slab) {              // halo hand-over: everyone is done reading Hs
+            wait_vmcnt<(RING == 3) ? DMA_OPS : 0>();                        // my halo loads have landed (the newer DMA batch stays in flight)
 #pragma unroll
             for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
             lds_barrier();
@@ -310,15 +328,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
     for (int slab = 0; slab < nslab; ++slab) {
         const bool next_slab = slab + 1 < nslab;
-        step(slab, next_slab, ic<0>{});
-        step(slab, next_slab, ic<1>{});
-        step(slab, next_slab, ic<2>{});
-        step(slab, next_slab, ic<3>{});
-        step(slab, next_slab, ic<4>{});
-        step(slab, next_slab, ic<5>{});
-        step(slab, next_slab, ic<6>{});
-        step(slab, next_slab, ic<7>{});
-        step(slab, next_slab, ic<8>{});
+        static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, tc); });
     }
     // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
     // destination registers -- hipcc does not know those registers have a write in flight.
@@ -331,7 +341,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     // fragment pairs are half-exchanged (widen_pair) so every lane stores 16 bytes = 8 consecutive channels;
     // otherwise 4 consecutive channels (8 bytes, fp32 16) of channel quad `lqc` per fragment.
     const T* __restrict__ res = (const T*)p.res;
-    const int ox = tx0 + lr;
+    const int sx = tx0 + lr;                         // tile-plane column of this lane; output column below
+    const int ox = SUBPIX ? 2 * sx + pb : sx;
     const bool do_stats = p.gn_part != nullptr;      // GroupNorm partial sums of the stored output (next layer's norm)
     float gs[FN], gq[FN];                            // per 4-channel quad this lane accumulates (wide: 2 per fragment pair)
     int gquad[FN];                                   // its quad index inside the wave's channel span (channel / 4)
@@ -350,9 +361,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                     const int n = n0 + wn * WTN + (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
-                        const int oy = ty0 + wm * FM + i;
+                        const int oy = SUBPIX ? 2 * (ty0 + wm * FM + i) + pa : ty0 + wm * FM + i;
                         const bool ok = ox < p.wo && oy < p.ho && n < p.N;
-                        const int64_t m = ((int64_t)img * p.ho + (ok ? oy : ty0)) * p.wo + (ok ? ox : tx0);
+                        const int64_t m = ((int64_t)img * p.ho + (ok ? oy : (SUBPIX ? 2 * ty0 + pa : ty0))) * p.wo + (ok ? ox : (SUBPIX ? 2 * tx0 + pb : tx0));
                         rres[i][jp] = *(const chunk_t*)(res + m * p.ldr + (ok ? n : 0));
                     }
                 }
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                 for (int i = 0; i < FM; ++i) {
                     float v[8];
                     widen_pair(acc[i][2 * jp], acc[i][2 * jp + 1], v);        // wave-wide: before any lane drops out
-                    const int oy = ty0 + wm * FM + i;
+                    const int oy = SUBPIX ? 2 * (ty0 + wm * FM + i) + pa : ty0 + wm * FM + i;
                     if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
                     const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
 #pragma unroll
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int oy = ty0 + wm * FM + i;
+                const int oy = SUBPIX ? 2 * (ty0 + wm * FM + i) + pa : ty0 + wm * FM + i;
                 if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
                 const int64_t m = ((int64_t)img * p.ho + oy) * p.wo + ox;
                 float v[4];
@@ -481,11 +492,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     }
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false>
 int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
-    const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN));
-    const size_t smem = ((TH + 2) * HW2 + 3 * BN) * 128 + 512;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
+    constexpr int KS = SUBPIX ? 2 : 3, RING = SUBPIX ? 2 : 3;
+    const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
+    const unsigned tiles = (unsigned)(((pl_w + TW - 1) / TW) * ((pl_h + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN)) * (SUBPIX ? 4u : 1u);
+    const size_t smem = ((TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + 512;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW, SUBPIX>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
     return i2i::check_launch("conv3x3_halo");
 }
 
@@ -515,6 +528,11 @@ void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
 
 template <typename T>
 int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
+    if (p.subpix) {      // sub-pixel upsampler: weights are [4 parities][N][4*cin], tiles walk the source plane
+        if (p.hin >= 16 && p.nimg * ((p.hin + 15) / 16) * ((p.win + 15) / 16) * ((p.N + 127) / 128) >= 128)
+            return launch_halo<T, 16, 128, 4, 2, 2, 2, true>(p, s);
+        return launch_halo<T, 8, 128, 2, 2, 2, 2, true>(p, s);
+    }
     const int cfg = halo_cfg(p);
     switch (cfg) {
         case 11: return launch_halo<T, 16, 128, 2, 2, 2, 1>(p, s);   // 4 waves x (8 rows x 64 ch), 1 workgroup / CU
@@ -540,6 +558,7 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.c0 % ck || p.c1 % ck || (p.c0 + p.c1) < ck) return false;
     if (p.wo < TW || p.ho < 8) return false;
     if (p.ho != (p.hin << p.ups) || p.wo != (p.win << p.ups)) return false;
+    if (p.subpix && (p.ups != 1 || p.win < TW || p.hin < 8 || p.ldb != 4 * (p.c0 + p.c1) || p.gn_part)) return false;
     if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     return true;
 }

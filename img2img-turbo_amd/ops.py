@@ -17,7 +17,7 @@ def ptr(t):
 
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
-         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None):
+         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0):
     """Implicit-GEMM conv / linear over NHWC sources.  ``w`` is packed [N][ks*ks*(c0+c1)]."""
     p = K.IgemmParams()
     c0 = x0.shape[-1] if c0 is None else c0
@@ -42,7 +42,7 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.ldc = ldc if ldc is not None else out.shape[-1]
     p.zcount, p.zh_count = 1, 1
     p.geglu, p.out_f32, p.tile = geglu, out_f32, tile
-    p.splitk, p.ws = splitk, ptr(ws)
+    p.splitk, p.ws, p.subpix = splitk, ptr(ws), subpix
     return K.OP_IGEMM, p
 
 

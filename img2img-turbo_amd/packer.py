@@ -21,6 +21,25 @@ def _pad8(c):
     return (c + 7) // 8 * 8
 
 
+def subpixel_weights(w):
+    """Sub-pixel form of ``conv3x3(nearest_upsample_2x(x))`` (diffusers Upsample2D.forward): the output pixel
+    (2y+a, 2x+b) only sees source pixels (y + a - 1 + r, x + b - 1 + c), r, c in {0, 1}, so per output parity the
+    nine taps collapse onto a 2x2 kernel whose weights are sums of the original taps.
+
+    ``w``: OIHW fp32 [O, I, 3, 3]  ->  [4 parities (a*2+b)][O][2][2][I] fp32 (k order (r, c, i), as the kernels read).
+    """
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    R = ((0, 1, 1), (0, 0, 1))     # R[a][dy] = source row offset r hit by tap dy for output parity a
+    out = torch.zeros(2, 2, o, 2, 2, i, dtype=torch.float32)
+    for a in range(2):
+        for b in range(2):
+            for dy in range(3):
+                for dx in range(3):
+                    out[a, b, :, R[a][dy], R[b][dx], :] += w[:, :, dy, dx].float()
+    return out.reshape(4, o, 2, 2, i)
+
+
 class Packer:
     def __init__(self, sd: Dict[str, torch.Tensor], scaling: Dict[str, float], dtype, device, r: float = 1.0):
         self.sd = sd
@@ -88,6 +107,17 @@ class Packer:
                 w = w[:, :, None, None]
             self.cache[key] = dict(w=self._up(self._conv_to_k(w, split)), b=None if b is None else self._up(b, torch.float32),
                                    n=w.shape[0], ks=w.shape[2])
+        return self.cache[key]
+
+    def conv_subpixel(self, name):
+        """Upsample2D conv in sub-pixel form: dict(w=[4*N][4*I] dtype, b, n, ks=3, subpix=True) (see subpixel_weights)."""
+        key = ("conv_subpix", name)
+        if key not in self.cache:
+            w, b = self.merged(name)
+            o, i = w.shape[0], w.shape[1]
+            assert i % 8 == 0
+            self.cache[key] = dict(w=self._up(subpixel_weights(w).reshape(4 * o, 4 * i)), b=None if b is None else self._up(b, torch.float32),
+                                   n=o, ks=3, subpix=True)
         return self.cache[key]
 
     def twin_conv_in(self):

@@ -72,7 +72,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         if (H // 8) % 8 or (W // 8) % 8:
             raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
@@ -83,6 +83,7 @@ class ForwardPlan:
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
         self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
+        self.subpix = subpix         # Upsample2D convs in sub-pixel form (4 parity 2x2 convs on the source plane)
         self.dma_small = dma_small   # non-halo GN convs: materialise GN and use the LDS-DMA igemm (+ split-K)
         self.ua, self.va = weights.unet_arch, weights.vae_arch
         vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
@@ -187,6 +188,14 @@ class ForwardPlan:
             return 0, None
         return sk, self.pool.get(sk * M * N, torch.float32)
 
+    def upsample_conv(self, pk, name, x: Act, label) -> Act:
+        """Upsample2D: nearest-2x + 3x3 conv.  Sub-pixel form (4/9 of the MACs, csrc/conv3x3.hip SUBPIX) whenever the
+        halo kernel takes it -- slab-aligned channels, source plane of at least one 8x16 tile; else the index-map gather."""
+        bk = 32 if self.dtype == torch.float32 else 64
+        if self.subpix and x.c % bk == 0 and x.h >= 8 and x.w >= 16:
+            return self.conv(pk.conv_subpixel(name), x, ups=1, label=label)
+        return self.conv(pk.conv(name), x, ups=1, label=label)
+
     def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, asym=False, x1: Optional[Act] = None, gn=False, act=0,
              res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
              label="") -> Act:
@@ -204,7 +213,8 @@ class ForwardPlan:
         if out is None:
             out = self.new(x.n, ho, wo, cp, torch.float32 if out_f32 else None)
         c1 = x1.c if x1 else 0
-        assert pw["w"].shape[1] == ks * ks * (x.c + c1), (label, pw["w"].shape, ks, x.c, c1)
+        subpix = 1 if pw.get("subpix") else 0
+        assert pw["w"].shape[1] == (4 if subpix else ks * ks) * (x.c + c1), (label, pw["w"].shape, ks, x.c, c1)
         x_in0, x_in1 = x, x1
         c0_eff, c1_eff = x.c, c1
         epc = 4 if self.dtype == torch.float32 else 8
@@ -231,7 +241,7 @@ class ForwardPlan:
                     x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
                     gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
                     res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
-                    splitk=splitk, ws=ws)
+                    splitk=splitk, ws=ws, subpix=subpix)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
         out.producer = op[1]
@@ -468,7 +478,7 @@ class ForwardPlan:
                     h2 = h3
                 h = h2
             if i < nb - 1:
-                h2 = self.conv(pk.conv(f"up_blocks.{i}.upsamplers.0.conv"), h, ups=1, label=f"up_blocks.{i}.upsamplers.0.conv")
+                h2 = self.upsample_conv(pk, f"up_blocks.{i}.upsamplers.0.conv", h, f"up_blocks.{i}.upsamplers.0.conv")
                 self.free(h)
                 h = h2
         assert not res
@@ -498,7 +508,7 @@ class ForwardPlan:
                 self.free(h)
                 h = h2
             if i < len(rboc) - 1:
-                h2 = self.conv(pk.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv"), h, ups=1, label=f"decoder.up_blocks.{i}.upsamplers.0.conv")
+                h2 = self.upsample_conv(pk, f"decoder.up_blocks.{i}.upsamplers.0.conv", h, f"decoder.up_blocks.{i}.upsamplers.0.conv")
                 self.free(h)
                 h = h2
         self.gn_stats(pk, "decoder.conv_norm_out", h, g, eps)

@@ -90,6 +90,9 @@ typedef struct {
                                   epilogue as [nimg][parts][gn_part_groups][2] = (sum, sum of squares) with
                                   parts = i2i_igemm_gn_parts(); finished by I2I_OP_GN_STATS with finalize_only */
     int32_t gn_part_groups;
+    int32_t subpix;            /* 1 (with ups = 1, ks = 3, stride 1, pad 1): `b` holds the SUB-PIXEL form of the
+                                  upsample+conv, [4 parities (a,b)][N][2*2*cin] with ldb = 4*cin, tap weights
+                                  pre-summed per output parity (packer.subpixel_weights); K stays 9*cin */
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.

@@ -60,7 +60,7 @@ def gn_scale_shift(x, groups, gamma, beta, eps):
 
 
 def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, stride=1, pad=1, ups=0,
-               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4, splitk=0):
+               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4, splitk=0, subpix=False):
     g = torch.Generator().manual_seed(seed)
     ct = cin + cin2
     x = torch.randn(n, ct, h, w, generator=g)
@@ -103,6 +103,10 @@ def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, st
     if cin2:
         wp[..., c0p:c0p + cin2] = wt[:, cin:].permute(0, 2, 3, 1)
     wp = wp.reshape(cout, -1).to(dtype).contiguous().to(device)
+    if subpix:     # product packing of the sub-pixel form; the reference above stays F.conv2d on the upsampled input
+        from img2img_turbo_amd.packer import subpixel_weights
+        assert ups == 1 and not cin2 and c0p == cin
+        wp = subpixel_weights(wt).reshape(4 * cout, 4 * cin).to(dtype).contiguous().to(device)
     ssd = None
     if gn:
         ssp = torch.zeros(n, c0p + c1p, 2)
@@ -117,7 +121,7 @@ def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, st
     wsd = torch.full((splitk * n * ho * wo * cout,), float("nan"), device=device) if splitk > 1 else None   # keep alive
     opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=ks, stride=stride, pad=kpad, ups=ups,
                        x1=x1, c0=c0p, c1=c1p, N=cout, gn_ss=ssd, act=act, bias=bd, alpha=alpha, res=rd, tile=tile,
-                       splitk=splitk, ws=wsd)
+                       splitk=splitk, ws=wsd, subpix=1 if subpix else 0)
     run_op(lib, opcode, p, dtype, device)
     got = out.cpu().float()[..., :cout].permute(0, 3, 1, 2)
     assert torch.isfinite(got).all(), "non-finite output"

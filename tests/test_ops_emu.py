@@ -171,3 +171,30 @@ def test_conv_epilogue_groupnorm_partials(emu_lib, cfg, dtype):
     """gn_part: per-tile partial sums from the conv epilogue + finalize_only == statistics of the stored tensor."""
     oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=cfg)      # ragged tiles
     oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=1, cin=64, cout=192, h=16, w=16, groups=12, tile=cfg, res=False)  # cpg 16, 2 n-tiles
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_subpixel_upsample_conv(emu_lib, dtype):
+    """Upsample2D in sub-pixel form (4 parity 2x2 convs over the source plane, tap weights pre-summed) against
+    F.conv2d on the nearest-upsampled input: ragged source planes, 2-3 slabs, bias + residual, N not a tile multiple."""
+    oc.check_conv(emu_lib, "cpu", dtype, n=2, cin=128, cout=72, h=9, w=20, ups=1, res=True, subpix=True)
+    oc.check_conv(emu_lib, "cpu", dtype, n=1, cin=64, cout=136, h=16, w=16, ups=1, subpix=True)     # 16-row tiles, 2 n-tiles
+
+
+def test_subpixel_weights_identity():
+    """packer.subpixel_weights: conv3x3(upsample2x(x)) == interleave of the four parity 2x2 convs (pure torch)."""
+    import torch.nn.functional as F
+    from img2img_turbo_amd.packer import subpixel_weights
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    ws = subpixel_weights(w.float()).double().reshape(2, 2, 4, 2, 2, 5)          # [a][b][o][r][c][i]
+    out = torch.zeros_like(ref)
+    xp = F.pad(x, (1, 1, 1, 1))
+    for a in range(2):
+        for b in range(2):
+            k = ws[a, b].permute(0, 3, 1, 2)                                        # [o][i][r][c]
+            y = F.conv2d(xp[:, :, a:a + 7, b:b + 8], k)                             # source window starts at (y+a-1, x+b-1)
+            out[:, :, a::2, b::2] = y
+    assert (out - ref).abs().max() < 1e-5

@@ -114,3 +114,10 @@ def test_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
     for dtype in (torch.bfloat16, torch.float32):
         oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=72, w=40, groups=32, tile=cfg)
         oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=64, cout=512, h=32, w=32, groups=32, tile=cfg, res=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_subpixel_upsample_conv(gpu_lib, dtype):
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=200, h=36, w=52, ups=1, res=True, subpix=True)   # 8-row tiles, ragged
+    oc.check_conv(gpu_lib, "cuda", dtype, n=8, cin=256, cout=256, h=64, w=64, ups=1, subpix=True)             # 16-row tiles
