@@ -41,12 +41,18 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {   
 // the source with the tap weights pre-summed (packer.subpixel_weights) -- 4/9 of the MFMA work, no index map.
 // A workgroup then owns TH x 16 SOURCE positions of one parity: halo (TH+1) x 17, 4 taps per slab, 2-deep weight
 // ring (4 % 3 != 0), outputs scattered to (2y+a, 2x+b).
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX>
+// DBH: double-buffered halo.  The next slab's halo is transformed and stored into the OTHER halo image one chunk
+// per tap, interleaved with the MFMAs of the current slab (chunk loaded in tap t's window, stored in tap t+1's), so
+// the serial hand-over (two barriers + the whole GroupNorm/SiLU pass with the matrix pipe idle) disappears and
+// only ~2 chunks are live in registers.  The LDS this costs is paid with a 2-deep weight ring (buffer = step
+// parity, toggled at run time because 9 taps is odd): (2 x halo + 2 x weights) of the 8x16x128 tile = 79 KiB,
+// still two workgroups per CU.
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX, bool DBH>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i2i_igemm_params p) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int CK = 8 * EPC;                      // channels per slab: 64 (16-bit) / 32 (f32)
-    constexpr int KS = SUBPIX ? 2 : 3, NTAPS = KS * KS, RING = SUBPIX ? 2 : 3;
+    constexpr int KS = SUBPIX ? 2 : 3, NTAPS = KS * KS, RING = (SUBPIX || DBH) ? 2 : 3;
     constexpr int HW2 = TW + KS - 1, HALO = (TH + KS - 1) * HW2;
     static_assert(TH % WM == 0 && BN % (16 * WN) == 0, "");
     constexpr int FM = TH / WM;                      // m-fragments per wave = tile rows per wave
@@ -89,9 +95,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
     const bool has_gn = p.gn_ss != nullptr;
 
-    char* Hs = i2i_smem;                             // [HALO] rows of 128 B (one slab)
-    char* Bs = i2i_smem + HALO * 128;                // [RING][BN] rows of 128 B (step s lives in buffer tap % RING)
-    char* Ss = Bs + RING * BN * 128;                    // [CK][2] fp32 GroupNorm (scale, shift) of the slab in flight
+    // LDS map.  DBH: weights first (so the buffer toggle is an XOR of the offset with BN*128), two halo images, two
+    // GroupNorm constant blocks.  Otherwise: one halo image, the weight ring, one constant block.
+    constexpr int BS0 = DBH ? 0 : HALO * 128;                        // [RING][BN] rows of 128 B
+    constexpr int HS0 = DBH ? RING * BN * 128 : 0;                   // [1 or 2][HALO] rows of 128 B (one slab each)
+    constexpr int SS0 = DBH ? HS0 + 2 * HALO * 128 : BS0 + RING * BN * 128;   // [1 or 2][CK][2] fp32 (scale, shift)
+    char* Hs = i2i_smem + HS0;
+    char* Bs = i2i_smem + BS0;
+    char* Ss = i2i_smem + SS0;
+    int hcur = 0;                                    // DBH: halo image / constant block of the slab being multiplied
 
     // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
     // One 32-bit pixel index per chunk (inside image `img`; ~0 = zero padding); the byte offset
@@ -141,9 +153,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     chunk_t rh[HPT];
 
     // GroupNorm (scale, shift) of the slab's CK channels: CK*8 bytes by LDS-DMA into Ss (one partial piece)
-    auto ss_dma = [&](int slab) __attribute__((always_inline)) {
+    auto ss_dma = [&](int slab, int sbuf) __attribute__((always_inline)) {
         if (wave == 0 && lane < CK / 2)
-            glds16(p.gn_ss + ((int64_t)img * cin + slab * CK) * 2 + lane * 4, Ss);
+            glds16(p.gn_ss + ((int64_t)img * cin + slab * CK) * 2 + lane * 4, Ss + sbuf * 512);
     };
     // One 16-byte load per call, ALWAYS and branch-free (padding lanes read pixel 0 of the image and are zeroed when
     // the halo is stored): the counted vmcnt waits rely on every wave issuing the same number of VMEM operations
@@ -157,35 +169,39 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         if (hidden) gload16_uncounted(rh[j], base, voff);
         else rh[j] = *(const chunk_t*)(base + voff);
     };
-    auto halo_store_all = [&]() __attribute__((always_inline)) {
-        float ssr[2 * EPC];
+    // GroupNorm affine + SiLU of one parked chunk, then its ds_write_b128 into halo image `hbuf`
+    auto halo_store_one = [&](int j, int hbuf, const float* ssr) __attribute__((always_inline)) {
+        const int hp = (tid >> 3) + j * (NT / 8);
+        if (hp < HALO) {
+            chunk_t c = (hpix[j] != ~0u) ? rh[j] : zero_chunk<T>();
+            if (has_gn && hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
+                float v[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = to_f32<T>(c[e]) * ssr[2 * e] + ssr[2 * e + 1];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = silu_f(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) c[e] = from_f32<T>(v[e]);
+            }
+            *(chunk_t*)(Hs + hbuf * HALO * 128 + lds_chunk_off2(hp, kc)) = c;
+        }
+    };
+    auto load_ssr = [&](float* ssr, int sbuf) __attribute__((always_inline)) {   // this thread's 8 channels (kc) of the block
         if (has_gn) {
 #pragma unroll
             for (int q = 0; q < EPC / 2; ++q) {
-                const f32x4 v = *(const f32x4*)(Ss + kc * EPC * 8 + q * 16);
+                const f32x4 v = *(const f32x4*)(Ss + sbuf * 512 + kc * EPC * 8 + q * 16);
                 ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
             }
         }
-        const bool silu = p.act == 1;
+    };
+    auto halo_store_all = [&]() __attribute__((always_inline)) {
+        float ssr[2 * EPC];
+        load_ssr(ssr, 0);
 #pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int hp = (tid >> 3) + j * (NT / 8);
-            if (hp < HALO) {
-                chunk_t c = (hpix[j] != ~0u) ? rh[j] : zero_chunk<T>();
-                if (has_gn && hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
-                    float v[EPC];
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] = to_f32<T>(c[e]) * ssr[2 * e] + ssr[2 * e + 1];
-                    if (silu) {
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[e] = silu_f(v[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) c[e] = from_f32<T>(v[e]);
-                }
-                *(chunk_t*)(Hs + lds_chunk_off2(hp, kc)) = c;
-            }
-        }
+        for (int j = 0; j < HPT; ++j) halo_store_one(j, 0, ssr);
     };
 
     f32x4 acc[FM][FN];
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     // ---- prologue: weights of steps 0..2 and the slab's GN constants by DMA, halo of slab 0 through registers ----
 #pragma unroll
     for (int t = 0; t < RING; ++t) b_dma(0, t, t);
-    if (has_gn) ss_dma(0);
+    if (has_gn) ss_dma(0, 0);
 #pragma unroll
     for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
     wait_vmcnt<0>();
@@ -216,11 +232,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     {
         const int u = wm * FM * HW2 + lr;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) x_off[m] = u * 128 + ((lq ^ lds_swz2(u + m)) << 4);
+        for (int m = 0; m < 8; ++m) x_off[m] = HS0 + u * 128 + ((lq ^ lds_swz2(u + m)) << 4);
     }
     // weight fragment row = wn*WTN + j*16 + lr (swizzle independent of j): base of buffer 0, k-group 0
     constexpr bool PERM = (EPC == 8) && (FN % 2 == 0);    // 16-bit outputs: weight rows permuted for 16-byte stores
-    const int w_off = lds_chunk_off2(wn * WTN + (PERM ? frag_row_perm(lr) : lr), lq) + HALO * 128;
+    int w_off = lds_chunk_off2(wn * WTN + (PERM ? frag_row_perm(lr) : lr), lq) + BS0;   // DBH: toggled per step (^ BN*128)
+    int bcur = 0;                                    // DBH: weight buffer of the current step (uniform)
 
     // ---- the step pipeline.  A step = one (slab, tap) = 2 k-groups x FM tile rows = 2*FM "row groups" of FN
     // MFMAs each.  Fragment reads run AHEAD of the MFMAs that use them, across k-groups and across the
@@ -244,6 +261,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     auto wf_read = [&](int tapv, int kg, int j) __attribute__((always_inline)) -> chunk_t {
         return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + (tapv % RING) * BN * 128 + j * 2048));
     };
+    // DBH: weight buffer = step parity; w_off already points at this step's buffer, `rel` = 1 reads the next step's
+    auto wf_read_t = [&](int rel, int kg, int j) __attribute__((always_inline)) -> chunk_t {
+        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64) ^ (rel * BN * 128)) + j * 2048));
+    };
 
     // One row group g of step `tap`: its prefetch reads, then its FN MFMAs (schedule pinned in that order).
     auto row_group = [&](auto tapc, auto gc, bool more) __attribute__((always_inline)) {
@@ -258,8 +279,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         // weight fragments: k-group 1 of this step during k-group 0, k-group 0 of the next step during k-group 1
 #pragma unroll
         for (int t = 0; t < nw; ++t) {
-            if constexpr (kg == 0) w1[j0 + t] = wf_read(tap, 1, j0 + t);
-            else if (more) w0[j0 + t] = wf_read(tap + 1, 0, j0 + t);
+            if constexpr (DBH) {
+                if constexpr (kg == 0) w1[j0 + t] = wf_read_t(0, 1, j0 + t);
+                else if (more) w0[j0 + t] = wf_read_t(1, 0, j0 + t);
+            } else {
+                if constexpr (kg == 0) w1[j0 + t] = wf_read(tap, 1, j0 + t);
+                else if (more) w0[j0 + t] = wf_read(tap + 1, 0, j0 + t);
+            }
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], xq[g % 4], acc[i][j]);
@@ -278,7 +304,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     auto step = [&](int slab, bool next_slab, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         const bool more = tap < NTAPS - 1 || next_slab;   // another step follows
-        if (tap == NTAPS - 2 && next_slab && has_gn) ss_dma(slab + 1);   // Ss was last read at the previous hand-over
+        if (!DBH && tap == NTAPS - 2 && next_slab && has_gn) ss_dma(slab + 1, 0);   // Ss was last read at the previous hand-over
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (tap == 0) {                         // first step of a slab: the halo image is new
 #pragma unroll
@@ -298,6 +324,35 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             wait_vmcnt<0>();                              // 2-deep ring: B[s+1] is the most recent batch
         }
         lds_barrier();
+        if constexpr (DBH) {
+            // -- window after P_s (every P waited vmcnt(0): the loads of the previous window have landed).
+            //    Chunks j = t, t+L, t+2L are loaded in tap t's window (t < L = NTAPS-2), transformed and stored
+            //    into the other halo image in tap t+1's window: the last store sits in tap L = NTAPS-2, so
+            //    P_{NTAPS-1} publishes the complete image before the next slab reads it.
+            constexpr int L = NTAPS - 2;
+            static_assert(3 * L >= HPT, "halo chunks do not fit the taps of a slab");
+            if constexpr (tap >= 1 && tap <= L) {
+                if (next_slab) {
+                    float ssr[2 * EPC];
+                    load_ssr(ssr, hcur ^ 1);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        constexpr int t0 = tap - 1;
+                        const int j = t0 + k * L;
+                        if (j < HPT) { reg_fence(rh[j]); halo_store_one(j, hcur ^ 1, ssr); }
+                    }
+                }
+            }
+            if constexpr (tap < L) {
+                const int hs = next_slab ? slab + 1 : slab;       // always issued: nothing downstream may count on a branch
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (tap + k * L < HPT) halo_load(hs, tap + k * L, true);
+            }
+            if (tap == 0 && next_slab && has_gn) ss_dma(slab + 1, hcur ^ 1);     // lands by P_1, first read in tap 1's window
+            // weights of step s+2 into the buffer this step just released
+            if (tap + 2 < NTAPS) b_dma(slab, tap + 2, bcur);
+            else if (next_slab) b_dma(slab + 1, tap + 2 - NTAPS, bcur);
+        } else {
         // -- window after P_s: next slab's halo into registers (uncounted loads; from the current slab again when
         //    there is no next one, so the count per window never changes), then the DMA of B[s+3] into the buffer
         //    just released.  Halo first: the hand-over then waits with vmcnt(DMA_OPS) and leaves the DMA in flight.
@@ -306,14 +361,24 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             if constexpr (tap < HPT) halo_load(hs, tap, true);
             if constexpr (tap + NTAPS < HPT) halo_load(hs, tap + NTAPS, true);
             if constexpr (tap + 2 * NTAPS < HPT) halo_load(hs, tap + 2 * NTAPS, true);
-            static_assert(3 * NTAPS >= HPT, "halo loads do not fit the taps of a slab");
+            static_assert(DBH || 3 * NTAPS >= HPT, "halo loads do not fit the taps of a slab");
         }
         if (tap + RING < NTAPS) b_dma(slab, tap + RING, tap % RING);
         else if (next_slab) b_dma(slab + 1, tap + RING - NTAPS, tap % RING);
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
         __builtin_amdgcn_sched_barrier(0);
-        if (tap == NTAPS - 1 && next_slab) {              // halo hand-over: everyone is done reading Hs
+        if constexpr (DBH) {
+            w_off ^= BN * 128;                            // next step multiplies the other weight buffer
+            bcur ^= 1;
+            if (tap == NTAPS - 1 && next_slab) {          // next slab multiplies the other halo image
+                const int d = hcur ? -(HALO * 128) : HALO * 128;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) x_off[m] += d;
+                hcur ^= 1;
+            }
+        } else if (tap == NTAPS - 1 && next_slab) {       // halo hand-over: everyone is done reading Hs
             wait_vmcnt<(RING == 3) ? DMA_OPS : 0>();                        // my halo loads have landed (the newer DMA batch stays in flight)
 #pragma unroll
             for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
@@ -325,7 +390,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 
     // first weights of the first step (every later step finds w0 preloaded by its predecessor)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
+    for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);     // buffer 0 in both layouts
     for (int slab = 0; slab < nslab; ++slab) {
         const bool next_slab = slab + 1 < nslab;
         static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, tc); });
@@ -492,13 +557,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     }
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false>
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false, bool DBH = false>
 int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
-    constexpr int KS = SUBPIX ? 2 : 3, RING = SUBPIX ? 2 : 3;
+    constexpr int KS = SUBPIX ? 2 : 3, RING = (SUBPIX || DBH) ? 2 : 3;
     const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
     const unsigned tiles = (unsigned)(((pl_w + TW - 1) / TW) * ((pl_h + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN)) * (SUBPIX ? 4u : 1u);
-    const size_t smem = ((TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + 512;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW, SUBPIX>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
+    const size_t smem = ((DBH ? 2 : 1) * (TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + (DBH ? 1024 : 512);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW, SUBPIX, DBH>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
     return i2i::check_launch("conv3x3_halo");
 }
 
@@ -518,8 +583,8 @@ int halo_cfg(const i2i_igemm_params& p) {
 void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     switch (cfg) {
         case 11: case 19: *th = 16; *bn = 128; *wtn = 64; break;
-        case 12: case 18: *th = 16; *bn = 128; *wtn = 64; break;
-        case 13: case 17: *th = 8; *bn = 128; *wtn = 64; break;
+        case 12: case 18: case 32: *th = 16; *bn = 128; *wtn = 64; break;
+        case 13: case 17: case 31: case 33: *th = 8; *bn = 128; *wtn = 64; break;
         case 14: *th = 16; *bn = 64; *wtn = 32; break;
         case 15: *th = 8; *bn = 64; *wtn = 32; break;
         default: *th = 8; *bn = 16; *wtn = 16; break;
@@ -544,6 +609,9 @@ int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
         case 17: return launch_halo<T, 8, 128, 2, 2, 3, 2>(p, s);    // as 13, prefetch distance 3
         case 18: return launch_halo<T, 16, 128, 4, 2, 3, 2>(p, s);   // as 12, prefetch distance 3
         case 19: return launch_halo<T, 16, 128, 2, 2, 3, 1>(p, s);   // as 11, prefetch distance 3
+        case 31: return launch_halo<T, 8, 128, 2, 2, 2, 2, false, true>(p, s);    // as 13, double-buffered halo + 2-deep ring
+        case 32: return launch_halo<T, 16, 128, 4, 2, 2, 2, false, true>(p, s);   // as 12, double-buffered halo
+        case 33: return launch_halo<T, 8, 128, 2, 2, 3, 2, false, true>(p, s);    // as 31, prefetch distance 3
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3: unknown tile config %d", cfg);
 }

@@ -106,7 +106,11 @@ template <typename C> __device__ __forceinline__ void reg_fence(C&) {}
 template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) {
     // s_nop 4: hipcc pads nothing inside an asm string, and the SGPR base / VGPR offset are usually written by the
     // SALU / VALU instructions just ahead (SALU-write -> VMEM-read of an SGPR needs 5 wait states)
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    // readfirstlane makes the base provably uniform for the "s" constraint (free when it already lives in SGPRs)
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(ub) : "memory");
 }
 template <typename C> __device__ __forceinline__ void reg_fence(C& x) { asm volatile("" : "+v"(x)); }
 #endif

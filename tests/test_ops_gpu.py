@@ -75,7 +75,7 @@ def test_halo_conv(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33])
 def test_halo_conv_every_tile_config(gpu_lib, cfg):
     """Every conv3x3.hip tile configuration on the real LDS-DMA path (the emulator copies synchronously, so
     only the GPU run can see a missing wait): ragged planes, 2-4 slabs, GN+SiLU, residual, concat, upsample."""
@@ -109,7 +109,7 @@ def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [12, 13, 17, 18])
+@pytest.mark.parametrize("cfg", [12, 13, 17, 18, 31, 32])
 def test_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
     for dtype in (torch.bfloat16, torch.float32):
         oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=72, w=40, groups=32, tile=cfg)
