@@ -27,7 +27,7 @@ class TurboGeneratorBase(torch.nn.Module):
     """Shared plumbing: plan cache, packer cache, boundary staging, text conditioning."""
 
     def __init__(self, weights: GeneratorWeights, device="cuda", dtype=torch.float32, lib=None,
-                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True):
+                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None):
         super().__init__()
         self.weights = weights
         self.device_ = torch.device(device)
@@ -40,6 +40,7 @@ class TurboGeneratorBase(torch.nn.Module):
         self.timesteps = self.sched.timesteps
         self.use_graph = use_graph and self.lib.backend == "gfx950"
         self.fuse_gn, self.flash = fuse_gn, flash
+        self.plan_options = dict(plan_options or {})   # extra ForwardPlan switches (tests / ablations): halo_min_tiles, subpix, ...
         self._plans = {}
         self._packers = {}
         self._caption_cache = {}
@@ -85,7 +86,7 @@ class TurboGeneratorBase(torch.nn.Module):
         if key not in self._plans:
             self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
                                            r=r_eff, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
-                                           flash=self.flash, packers=self._get_packers(r_eff, direction))
+                                           flash=self.flash, packers=self._get_packers(r_eff, direction), **self.plan_options)
         return self._plans[key]
 
     def encode_prompt(self, prompt=None, prompt_tokens=None):

@@ -72,7 +72,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         if (H // 8) % 8 or (W // 8) % 8:
             raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
@@ -83,6 +83,7 @@ class ForwardPlan:
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
         self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
+        self.halo_min_tiles = halo_min_tiles   # fewer halo-conv tiles than this: LDS-DMA igemm + split-K instead
         self.subpix = subpix         # Upsample2D convs in sub-pixel form (4 parity 2x2 convs on the source plane)
         self.dma_small = dma_small   # non-halo GN convs: materialise GN and use the LDS-DMA igemm (+ split-K)
         self.ua, self.va = weights.unet_arch, weights.vae_arch
@@ -222,6 +223,13 @@ class ForwardPlan:
         # mirrors conv3x3_halo_eligible (csrc/conv3x3.hip): those convolutions apply GN+SiLU while staging the halo
         halo = (ks == 3 and stride == 1 and pad == 1 and not asym and not geglu and x.c % bk == 0 and c1 % bk == 0
                 and wo >= 16 and ho >= 8)
+        # ... but a halo launch that cannot fill the chip (few 8x16x128 tiles: the 16x16 / 32x32 UNet planes at
+        # small batch) is a weight-streaming problem: the LDS-DMA igemm with split-K takes it (tile 20 forces it)
+        force_tile = 0
+        if halo and not pw.get("subpix"):
+            halo_tiles = x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128)
+            if halo_tiles < self.halo_min_tiles:
+                halo, force_tile = False, 20
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
         if gn and not fused:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
@@ -241,7 +249,7 @@ class ForwardPlan:
                     x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
                     gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
                     res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
-                    splitk=splitk, ws=ws, subpix=subpix)
+                    splitk=splitk, ws=ws, subpix=subpix, tile=force_tile)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
         out.producer = op[1]

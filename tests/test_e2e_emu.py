@@ -47,3 +47,14 @@ def test_cyclegan_b2a_fp32(emu_lib):
     out = model(x, direction="b2a", caption_emb=cap, eps=eps)
     err = (out - ref).abs().max().item()
     assert err < 1e-3, err
+
+
+@pytest.mark.slow
+def test_pix2pix_halo_everywhere_fp32(emu_lib):
+    """Same forward with every eligible 3x3 conv on the halo kernel (tiny planes default to the split-K igemm)."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib, plan_options=dict(halo_min_tiles=0))
+    out = model(x, caption_enc=cap, eps=eps)
+    assert (out - ref).abs().max().item() < 1e-3

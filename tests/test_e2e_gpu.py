@@ -57,6 +57,18 @@ def test_tiny_unfused_paths_agree(gpu_lib):
         assert report(f"tiny fuse_gn={fuse_gn} flash={flash}", out, ref) < 1e-3
 
 
+def test_tiny_planner_routes_agree(gpu_lib):
+    """Planner switches that move work between kernels must not move the answer: halo conv for every eligible 3x3
+    (the tiny planes would otherwise all go to the split-K LDS-DMA igemm), no sub-pixel upsampler, no fused GN stats."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 2, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    for opts in (dict(halo_min_tiles=0), dict(halo_min_tiles=0, subpix=False, fuse_gn_stats=False), dict(dma_small=False, halo_min_tiles=0)):
+        model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32, plan_options=opts)
+        out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+        assert report(f"tiny plan_options={opts}", out, ref) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tiny_stochastic_twinconv(gpu_lib, dtype):
     mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
