@@ -233,8 +233,97 @@ __global__ __launch_bounds__(256) void softmax_kernel(const i2i_softmax_params p
     for (int c = lane; c < p.ldp; c += 64) o[c] = (c < p.cols) ? from_f32<T>(__expf(s[c] * p.scale - mx) * inv) : from_f32<T>(0.f);
 }
 
+// Single-launch GroupNorm statistics for the small tensors (UNet levels, VAE mid block): one workgroup owns `gpb`
+// groups of one image, streams their channels over every pixel, reduces through LDS in a fixed order and writes the
+// per-channel (scale, shift) itself -- the two-stage partial + finalize pair costs two launches of a few
+// microseconds each, which at batch 1 is a fifth of the whole forward.
+// Threads: U = gpb*cpg/8 eight-channel units per pixel, 256/U pixels per sweep.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_params p, int gpb) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int tid = threadIdx.x, img = blockIdx.x, g0 = blockIdx.y * gpb;
+    const int ct = p.c0 + p.c1, cpg = ct / p.groups;
+    const int nch = gpb * cpg, c_first = g0 * cpg;          // this block's channel range (multiple of 8: host check)
+    const int U = nch >> 3, ppb = 256 / U;
+    const int unit = tid % U, prow = tid / U;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (prow < ppb) {
+        const int c = c_first + unit * 8;
+        const T* src = (c < p.c0) ? (const T*)p.x0 + (int64_t)img * p.hw * p.ld0 + c
+                                  : (const T*)p.x1 + (int64_t)img * p.hw * p.ld1 + (c - p.c0);
+        const int ld = (c < p.c0) ? p.ld0 : p.ld1;
+        // four pixels per trip: four independent 16-byte loads in flight per thread (a lone dependent stream of
+        // loads is latency bound at ~20 GB/s per workgroup)
+        constexpr int UNR = 4;
+        for (int px0 = prow; px0 < p.hw; px0 += ppb * UNR) {
+            chunk_t v[UNR][8 / EPC];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int px = px0 + u * ppb;
+#pragma unroll
+                for (int h = 0; h < 8 / EPC; ++h)
+                    v[u][h] = (px < p.hw) ? *(const chunk_t*)(src + (int64_t)px * ld + h * EPC) : zero_chunk<T>();
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int h = 0; h < 8 / EPC; ++h)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float f = to_f32<T>(v[u][h][e]);
+                        s[h * EPC + e] += f;
+                        q[h * EPC + e] += f * f;
+                    }
+        }
+    }
+    float* red = (float*)i2i_smem;                // [256][16]
+    float* chs = red + 256 * 16;                  // [nch][2]
+    float* gst = chs + 2 * nch;                   // [gpb][2] mean, rstd
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {        // per-channel totals over the pixel rows, fixed order
+        const int u = c >> 3, e = c & 7;
+        float S = 0.f, Q = 0.f;
+        for (int r = 0; r < ppb; ++r) { S += red[(r * U + u) * 16 + e]; Q += red[(r * U + u) * 16 + 8 + e]; }
+        chs[2 * c] = S; chs[2 * c + 1] = Q;
+    }
+    __syncthreads();
+    if (tid < gpb) {
+        float S = 0.f, Q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { S += chs[2 * c]; Q += chs[2 * c + 1]; }
+        const float inv = 1.0f / ((float)cpg * (float)p.hw);
+        const float mu = S * inv;
+        const float var = fmaxf(Q * inv - mu * mu, 0.f);
+        gst[2 * tid] = mu;
+        gst[2 * tid + 1] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {
+        const int g = c / cpg, cc = c_first + c;
+        const float sc = gst[2 * g + 1] * p.gamma[cc];
+        float* o = p.ss + ((int64_t)img * ct + cc) * 2;
+        o[0] = sc;
+        o[1] = p.beta[cc] - gst[2 * g] * sc;
+    }
+}
+
 template <typename T>
 int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
+    {   // small tensors: one launch (see gn_stats_small_kernel)
+        const int ct0 = p.c0 + p.c1, cpg = ct0 / p.groups;
+        int gpb = 0;
+        for (int cand = 4; cand <= 16 && !gpb; cand <<= 1)      // fewest groups per block whose channels form whole 8-channel units
+            if (p.groups % cand == 0 && (cand * cpg) % 8 == 0 && (cand * cpg) / 8 <= 256) gpb = cand;                 // (a block may straddle the two sources: every 8-channel unit picks its own)
+        if (!p.finalize_only && gpb && (int64_t)p.hw * ct0 <= (3 << 20)) {
+            const size_t smem = (256 * 16 + 2 * gpb * cpg + 2 * gpb) * sizeof(float);
+            hipLaunchKernelGGL((gn_stats_small_kernel<T>), dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256), smem, s, p, gpb);
+            return i2i::check_launch("gn_stats_small");
+        }
+    }
     const int ct = p.c0 + p.c1;
     if (!p.finalize_only) {
         hipLaunchKernelGGL((gn_partial_kernel<T>), dim3((unsigned)p.nparts, (unsigned)p.nimg), dim3(256), (size_t)ct * 8, s, p);

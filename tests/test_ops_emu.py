@@ -198,3 +198,10 @@ def test_subpixel_weights_identity():
             y = F.conv2d(xp[:, :, a:a + 7, b:b + 8], k)                             # source window starts at (y+a-1, x+b-1)
             out[:, :, a::2, b::2] = y
     assert (out - ref).abs().max() < 1e-5
+
+
+def test_gn_stats_single_launch_shapes(emu_lib):
+    """gn_stats_small_kernel: channel ranges of a block that straddle the concat seam, cpg not a multiple of 8."""
+    oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, c0=640, c1=320, groups=32, h=4, w=4, nparts=1, n=2)    # cpg 30, seam inside a block
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=1280, c1=1280, groups=32, h=2, w=2, nparts=1, n=1)   # cpg 80
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=128, groups=32, h=16, w=8, nparts=2, n=2)            # cpg 4 (VAE)
