@@ -39,37 +39,44 @@ def synth_inputs(B, size, cross_dim, lat, device, seed):
 
 
 def kernel_roofline(plan, dtype_name, reps=2):
-    """HIP-event time of every launch of the program (i2i_run_timed, same stream the kernels run on);
-    the dominant kernel family = the 3x3 implicit-GEMM convolutions."""
-    from img2img_turbo_amd import _capi as K
+    """HIP-event time of every launch of the program (i2i_run_timed: events recorded on the stream the kernels
+    run on), grouped by the HIP kernel each op resolves to (plan.op_kernel).  The dominant kernel is the halo-tiled
+    3x3 convolution (csrc/conv3x3.hip): `achieved` = its ALGORITHMIC FLOPs (2*9*Cin*Cout per output pixel, SURVEY
+    Appendix B) / its measured time; the sub-pixel upsampler launches execute 4/9 of their algorithmic MACs."""
     ms = None
     for _ in range(reps):
         cur = plan.run_timed()
         ms = cur if ms is None else [min(a, b) for a, b in zip(ms, cur)]
     tot = sum(ms)
     fam = {}
-    for (opcode, _dt, p, label), t, fl in zip(plan.prog.ops, ms, plan.op_flops):
-        if opcode == K.OP_IGEMM:
-            name = "igemm_conv3x3" if p.ks == 3 else ("igemm_1x1/linear" if p.zcount == 1 else "igemm_batched")
-        else:
-            name = {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax", K.OP_ATTENTION: "attention",
-                    K.OP_GN_APPLY: "gn_apply"}.get(opcode, "elementwise")
+    for name, t, fl in zip(plan.op_kernel, ms, plan.op_flops):
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += t
         f[1] += fl
         f[2] += 1
     if PER_OP_PATH:
-        rows = sorted(((t, label, opc, fl) for (opc, _dt, _p, label), t, fl in zip(plan.prog.ops, ms, plan.op_flops)), reverse=True)
+        rows = sorted(((t, label, kn, fl) for (opc, _dt, _p, label), kn, t, fl in zip(plan.prog.ops, plan.op_kernel, ms, plan.op_flops)), reverse=True)
         with open(PER_OP_PATH, "w") as f:
-            for t, label, opc, fl in rows:
-                f.write("%8.4f ms  %7.1f TF  op%-2d %s\n" % (t, fl / (t * 1e-3) / 1e12 if t > 0 else 0.0, opc, label))
-    t3, f3, n3 = fam["igemm_conv3x3"]
+            for t, label, kn, fl in rows:
+                f.write("%8.4f ms  %7.1f TF  %-28s %s\n" % (t, fl / (t * 1e-3) / 1e12 if t > 0 else 0.0, kn[:28], label))
+    halo = [k for k in fam if k.startswith("conv3x3_halo_kernel")]
+    t3 = sum(fam[k][0] for k in halo)
+    f3 = sum(fam[k][1] for k in halo)
+    n3 = sum(fam[k][2] for k in halo)
     achieved = f3 / (t3 * 1e-3) / 1e12
     peak = PEAK_TF[dtype_name]
-    roof = {"bound": "mfma", "kernel": "igemm_kernel (3x3 implicit-GEMM conv)", "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "launches": n3,
-            "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),
-            "flops_per_step": f3}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic_conv3x3_halo.json")     # written by tools/pmc_traffic.py from a PMC run of THIS command
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name:
+            traffic = tj["hbm_bytes_per_launch"]
+    roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel (halo-tiled 3x3 implicit-GEMM conv, incl. sub-pixel upsampler form)",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, MI355X_MICROARCH.md HBM section)",
+            "launches": n3, "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),
+            "algorithmic_flops_per_launch": f3 / n3, "executed_mfma_flops_per_step": getattr(plan, "halo_flops_real", None)}
     breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None}
                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     return roof, breakdown, tot

@@ -97,6 +97,7 @@ class ForwardPlan:
         self.taps = {}          # label -> Act of that op's output (meaningful with debug=True)
         self.prog = K.Program()
         self.op_flops = []      # algorithmic FLOPs per op (2*MAC), parallel to prog.ops
+        self.op_kernel = []     # HIP kernel each op resolves to (reporting only), parallel to prog.ops
         self.flops = 0
         self.gn_partial = None
         self.gn_ss = None
@@ -120,9 +121,14 @@ class ForwardPlan:
         self.graph = None
 
     # ------------------------------------------------------------------ helpers
-    def _add(self, op, label, flops=0):
+    def _add(self, op, label, flops=0, kernel=None):
+        """Record one launch.  ``kernel``: which HIP kernel the C dispatcher will pick for an igemm op (the planner
+        mirrors csrc eligibility), used only for reporting (bench.py groups timings by kernel)."""
         self.prog.add(op[0], self.dt, op[1], label)
         self.op_flops.append(flops)
+        self.op_kernel.append(kernel or {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax",
+                                        K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply",
+                                        K.OP_IGEMM: "igemm_dma_kernel"}.get(op[0], "boundary/elementwise"))
 
     def new(self, n, h, w, c, dtype=None):
         t = self.pool.get(n * h * w * c, dtype or self.dtype)
@@ -257,7 +263,11 @@ class ForwardPlan:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
         fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
-        self._add(op, label, fl)
+        kname = ("conv3x3_halo_kernel<SUBPIX>" if subpix else "conv3x3_halo_kernel") if halo else \
+                ("igemm_kernel (register-staged, GN prologue)" if fused else "igemm_dma_kernel")
+        if halo:
+            self.halo_flops_real = getattr(self, "halo_flops_real", 0) + (fl * 4 // 9 if subpix else fl)
+        self._add(op, label, fl, kernel=kname)
         self.taps[label] = out
         if gn and not fused:
             self.free(x_in0)
