@@ -185,6 +185,185 @@ __global__ __launch_bounds__(256) void attention_kernel(const i2i_attention_para
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA flash attention for the 16-bit types (d = 64).  Same swapped-matmul scheme as attention_kernel
+// (softmax lane-local), different engine:
+//   * a wave owns 32 queries (two query fragments): every K / V^T fragment read from LDS feeds two MFMAs, half the
+//     LDS traffic per FLOP of the 16-query version; workgroup = 4 waves = 128 queries;
+//   * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] (8 KiB each) arrive by global_load_lds_dwordx4 into a
+//     3-stage ring, issued two tiles ahead, waited for with a counted vmcnt; ONE raw barrier per key tile;
+//   * scores are scaled by scale*log2(e) once and exponentiated with v_exp_f32 (2^x) directly;
+//   * rows / chunks past tk read a 16-byte zero block; the partially valid last V^T chunk (tk % 8 != 0) is cleaned
+//     in LDS before use (its padding may hold anything, and 0 * NaN would poison the output).
+__device__ __attribute__((aligned(16))) uint32_t g_att_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attention_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    static_assert(Elem<T>::EPC == 8, "16-bit types only");
+    constexpr int D = 64, BKV = 64, QF = 2, STAGE = 2 * BKV * 128, PPW = 4;   // 16 one-KiB pieces per stage, 4 per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
+    const char* vp = (const char*)((const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)h * D * p.ldvt);
+    const char* zero = (const char*)g_att_zero16;
+    const int ntile = (p.tk + BKV - 1) / BKV;
+
+    // this wave's DMA pieces: pc = wave*4 + q; pc < 8: K rows pc*8.. (row = key), else V^T rows (pc-8)*8.. (row = d)
+    auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
+        const int kv0 = t * BKV;
+        char* dst = i2i_smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int pc = wave * PPW + q;
+            const int row = (pc & 7) * 8 + (lane >> 3);
+            const int sc = (lane & 7) ^ ((row >> 1) & 7);                 // source chunk of physical chunk lane&7 (att_off<8>)
+            const char* src;
+            if (pc < 8) {
+                const int key = kv0 + row;
+                src = key < p.tk ? kp + ((size_t)key * p.ldk + sc * 8) * sizeof(T) : zero;
+            } else {
+                const int key0 = kv0 + sc * 8;
+                src = key0 < p.tk ? vp + ((size_t)row * p.ldvt + key0) * sizeof(T) : zero;
+            }
+            glds16(src, dst + pc * 1024);
+        }
+    };
+
+    // Q^T fragments (B operand of S^T = K Q^T): query q0 + 16*qf + lr, chunk kg*4 + lq
+    chunk_t qfr[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int qi = q0 + f * 16 + lr;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+            qfr[f][kg] = (qi < p.tq) ? *(const chunk_t*)(qp + (int64_t)qi * p.ldq + (kg * 4 + lq) * 8) : zero_chunk<T>();
+    }
+    f32x4 oacc[QF][4];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
+    const float c2 = p.scale * 1.44269504088896341f;       // scores in log2 units: p = 2^(s*c2 - m)
+
+    dma_tile(0, 0);
+    if (ntile > 1) dma_tile(1, 1);
+    for (int t = 0; t < ntile; ++t) {
+        const int st = t % 3, kv0 = t * BKV;
+        // tile t landed (leave the batch of tile t+1 in flight), everyone is done with tile t-1 -> its slot is free
+        if (t + 1 < ntile) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        lds_barrier();
+        if (t + 2 < ntile) dma_tile(t + 2, (t + 2) % 3);
+        const char* Ks = i2i_smem + st * STAGE;
+        const char* Vs = Ks + BKV * 128;
+        if (kv0 + BKV > p.tk && (p.tk & 7)) {              // last tile, partially valid V^T chunk: clean its tail in LDS
+            const int kc = (p.tk - kv0) >> 3, first = (p.tk - kv0) & 7;          // chunk index inside the tile, valid elements
+            if (tid < D) {
+                T* e = (T*)(i2i_smem + st * STAGE + BKV * 128 + att_off<8>(tid, kc));
+                for (int j = first; j < 8; ++j) e[j] = (T)0.0f;
+            }
+            lds_barrier();
+        }
+        // ---- S^T = K Q^T : sacc[f][kf][r] = S[query q0+16f+lr][key kv0 + 16kf + 4lq + r] ----
+        f32x4 sacc[QF][4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            chunk_t ka[2];
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) ka[kg] = *(const chunk_t*)(Ks + att_off<8>(kf * 16 + lr, kg * 4 + lq));
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) a = mma_chunk(ka[kg], qfr[f][kg], a);
+                sacc[f][kf] = a;
+            }
+        }
+        // ---- online softmax, lane-local per query apart from two xor-shuffles for the max ----
+        const bool tail = kv0 + BKV > p.tk;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mt = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = sacc[f][kf][r] * c2;
+                    if (tail && kv0 + kf * 16 + lq * 4 + r >= p.tk) sv = -1e30f;
+                    sacc[f][kf][r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run[f], mt);
+            const float alpha = exp2_fast(m_run[f] - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2_fast(sacc[f][kf][r] - m_new);
+                    sacc[f][kf][r] = pv;
+                    psum += pv;
+                }
+            l_run[f] = l_run[f] * alpha + psum;             // per-lane partial; quads are summed once at the end
+            m_run[f] = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
+        }
+        // ---- O^T += V^T P^T : keys 32g + 4lq..+3 and 32g + 16 + 4lq..+3 of V^T row 16i + lr ----
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            chunk_t pb[QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) pb[f] = pack_p(sacc[f][2 * g], sacc[f][2 * g + 1], T());
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + lr;
+                union { chunk_t c; uint64_t u[2]; } a;
+                a.u[0] = *(const uint64_t*)(Vs + att_off<8>(row, g * 4 + (lq >> 1)) + (lq & 1) * 8);
+                a.u[1] = *(const uint64_t*)(Vs + att_off<8>(row, g * 4 + 2 + (lq >> 1)) + (lq & 1) * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) oacc[f][i] = mma_chunk(a.c, pb[f], oacc[f][i]);
+            }
+        }
+    }
+    // ---- finalize: sum the per-quad partial row sums, normalise, store 4 consecutive d per lane ----
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l_tot = l_run[f];
+        l_tot += __shfl_xor(l_tot, 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + f * 16 + lr;
+        if (qi < p.tq) {
+            T* op = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D;
+            typedef T tx4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[f][i][r] * inv);
+                *(tx4*)(op + i * 16 + lq * 4) = o;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_att_dma(const i2i_attention_params& p, hipStream_t s) {
+    const dim3 grid((unsigned)((p.tq + 127) / 128), (unsigned)p.heads, (unsigned)p.batch);
+    hipLaunchKernelGGL((attention_dma_kernel<T>), grid, dim3(256), (size_t)3 * 2 * 64 * 128, s, p);
+    return i2i::check_launch("attention_dma");
+}
+
 template <typename T>
 int launch_att(const i2i_attention_params& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.tq + 63) / 64), (unsigned)p.heads, (unsigned)p.batch);
@@ -203,10 +382,14 @@ extern "C" int i2i_attention(const i2i_attention_params* p, int dtype, void* str
         return i2i::fail(I2I_ERR_BAD_ARG, "attention: bad leading dims");
     if (p->ldvt < ((p->tk + epc - 1) / epc) * epc) return i2i::fail(I2I_ERR_BAD_ARG, "attention: ldvt must cover tk rounded up to a chunk");
     hipStream_t s = (hipStream_t)stream;
+    // 16-bit types: LDS-DMA kernel (needs 8-byte aligned output rows for its vector stores); f32 parity mode: the
+    // register-staged kernel
+    const bool dma_ok = (p->ldo % 4 == 0) && (p->o_bs % 4 == 0) && (((uintptr_t)p->o & 7) == 0) && (((uintptr_t)p->k | (uintptr_t)p->vt) & 15) == 0 &&
+                        (p->ldk % 8 == 0) && (p->k_bs % 8 == 0) && (p->vt_bs % 8 == 0);
     switch (dtype) {
         case I2I_F32: return launch_att<float>(*p, s);
-        case I2I_BF16: return launch_att<__bf16>(*p, s);
-        case I2I_F16: return launch_att<_Float16>(*p, s);
+        case I2I_BF16: return dma_ok ? launch_att_dma<__bf16>(*p, s) : launch_att<__bf16>(*p, s);
+        case I2I_F16: return dma_ok ? launch_att_dma<_Float16>(*p, s) : launch_att<_Float16>(*p, s);
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "attention: bad dtype");
 }

@@ -62,7 +62,22 @@ __device__ __forceinline__ f32x4 mma_chunk(f16x8 a, f16x8 b, f32x4 acc) {
 
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the IEEE division sequence costs ~10 more VALU per element)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+#ifdef I2I_EMU
+__device__ __forceinline__ float exp2_fast(float x) { return exp2f(x); }
+#else
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32 (2^x, ~1 ulp)
+#endif
+// Exact-form GELU (F.gelu default, erf based) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32
+// round-off class): one v_rcp_f32 + one v_exp_f32 + 8 FMAs instead of libm's erff (~40 VALU) -- the GEGLU epilogue
+// of the ff.net.0 GEMMs evaluates it 4 times per accumulator fragment and was VALU bound.
+__device__ __forceinline__ float erf_as_f(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * exp2_fast(-1.44269504088896341f * ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f)); }
 
 // LDS tile geometry common to A and B tiles: rows of 128 bytes = 8 chunks; chunk kc of row r is stored
 // at physical chunk kc ^ ((r >> 1) & 7).  With this XOR a ds_read_b128 wave access (lane -> row l&15,

@@ -311,6 +311,54 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
     }
 }
 
+// Row softmax with the row held in registers (cols <= 4096, multiple of 4, 16-byte aligned rows): one read of the
+// fp32 scores as float4, one write of the probabilities as 4-element vectors.  The generic kernel above makes three
+// passes over the row and scalar accesses.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_row_kernel(const i2i_softmax_params p) {
+    constexpr int JM = 16;                                   // float4 per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const f32x4* s4 = (const f32x4*)(p.s + row * p.lds);
+    const int n4 = p.cols >> 2;
+    f32x4 v[JM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+        const int c = lane + j * 64;
+        if (c < n4) {
+            v[j] = s4[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] *= p.scale; mx = fmaxf(mx, v[j][e]); }
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+        if (lane + j * 64 < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = __expf(v[j][e] - mx); sum += v[j][e]; }
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    tx4* o4 = (tx4*)((T*)p.p + row * p.ldp);
+    const int np4 = p.ldp >> 2;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+        const int c = lane + j * 64;
+        if (c < np4) {
+            tx4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (c < n4) ? from_f32<T>(v[j][e] * inv) : from_f32<T>(0.f);
+            o4[c] = o;
+        }
+    }
+}
+
 template <typename T>
 int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
     {   // small tensors: one launch (see gn_stats_small_kernel)
@@ -388,6 +436,15 @@ extern "C" int i2i_softmax(const i2i_softmax_params* p, int dtype, void* stream)
     if (p->cols < 1 || p->ldp < p->cols) return i2i::fail(I2I_ERR_BAD_ARG, "softmax: bad cols");
     const unsigned grid = (unsigned)((p->rows + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+    if (p->cols % 4 == 0 && p->cols <= 4096 && p->ldp % 4 == 0 && p->ldp <= 4096 && p->lds % 4 == 0 && (((uintptr_t)p->s & 15) == 0) && (((uintptr_t)p->p & 15) == 0)) {
+        switch (dtype) {
+            case I2I_F32: hipLaunchKernelGGL((softmax_row_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
+            case I2I_BF16: hipLaunchKernelGGL((softmax_row_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;
+            case I2I_F16: hipLaunchKernelGGL((softmax_row_kernel<_Float16>), dim3(grid), dim3(256), 0, s, *p); break;
+            default: return i2i::fail(I2I_ERR_BAD_ARG, "softmax: bad dtype");
+        }
+        return i2i::check_launch("softmax_row");
+    }
     switch (dtype) {
         case I2I_F32: hipLaunchKernelGGL((softmax_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
         case I2I_BF16: hipLaunchKernelGGL((softmax_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;

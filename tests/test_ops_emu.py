@@ -205,3 +205,18 @@ def test_gn_stats_single_launch_shapes(emu_lib):
     oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, c0=640, c1=320, groups=32, h=4, w=4, nparts=1, n=2)    # cpg 30, seam inside a block
     oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=1280, c1=1280, groups=32, h=2, w=2, nparts=1, n=1)   # cpg 80
     oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=128, groups=32, h=16, w=8, nparts=2, n=2)            # cpg 4 (VAE)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_dma_ring_and_tails(emu_lib, dtype):
+    """attention_dma_kernel: >3 key tiles (ring wrap-around), query tails across workgroups, tk a multiple of 64,
+    tk with a partially valid last V^T chunk (padding poisoned with NaN by the checker)."""
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=2, tq=130, tk=264)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, tq=33, tk=64)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, tq=128, tk=325, spike=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_row_kernel(emu_lib, dtype):
+    oc.check_softmax(emu_lib, "cpu", dtype, rows=9, cols=256, ldp=256)        # register-resident path
+    oc.check_softmax(emu_lib, "cpu", dtype, rows=5, cols=1024, ldp=1032)      # zero padding past cols

@@ -121,3 +121,18 @@ def test_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
 def test_subpixel_upsample_conv(gpu_lib, dtype):
     oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=200, h=36, w=52, ups=1, res=True, subpix=True)   # 8-row tiles, ragged
     oc.check_conv(gpu_lib, "cuda", dtype, n=8, cin=256, cout=256, h=64, w=64, ups=1, subpix=True)             # 16-row tiles
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_dma_large(gpu_lib, dtype):
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=5, tq=4096, tk=4096)     # UNet level 0 self-attention
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=2, tq=130, tk=325, spike=True)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=3, heads=20, tq=64, tk=77)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_row_kernel(gpu_lib, dtype):
+    oc.check_softmax(gpu_lib, "cuda", dtype, rows=4099, cols=4096, ldp=4096)
+    oc.check_softmax(gpu_lib, "cuda", dtype, rows=130, cols=1024, ldp=1032)
