@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libi2i_turbo.so")
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, U8 = 0, 1, 2, 3
 OP_IGEMM, OP_GN_STATS, OP_LAYERNORM, OP_SOFTMAX = 1, 2, 3, 4
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY = 5, 6, 7, 8, 9, 10
 
@@ -65,7 +65,7 @@ class NchwToNhwcParams(C.Structure):
 
 class NhwcToNchwParams(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("n", i32), ("c", i32), ("h", i32), ("w", i32), ("ldx", i32),
-                ("dst_dtype", i32), ("clamp", i32)]
+                ("dst_dtype", i32), ("clamp", i32), ("mul", f32), ("add", f32)]
 
 
 class PosteriorParams(C.Structure):

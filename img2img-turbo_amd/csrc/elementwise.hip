@@ -33,6 +33,34 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const i2i_nhwc_to_nch
     }
 }
 
+// uint8 HWC image batch -> NHWC `T` (channels padded with zeros): F.to_tensor (+ Normalize) of the callers folded in
+template <typename T>
+__global__ __launch_bounds__(256) void u8hwc_to_nhwc_kernel(const i2i_nchw_to_nhwc_params p) {
+    const int64_t total = (int64_t)p.n * p.h * p.w;
+    const float k = p.mul * (1.0f / 255.0f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const uint8_t* x = (const uint8_t*)p.x + i * p.c;
+        T* y = (T*)p.y + i * p.cpad;
+        for (int c = 0; c < p.cpad; ++c) y[c] = (c < p.c) ? from_f32<T>((float)x[c] * k + p.add) : from_f32<T>(0.f);
+    }
+}
+// NHWC `T` -> uint8 HWC: clamp, x*mul+add, ToPILImage's mul(255).byte() (truncation)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_u8hwc_kernel(const i2i_nhwc_to_nchw_params p) {
+    const int64_t total = (int64_t)p.n * p.h * p.w;
+    const float mul = (p.mul == 0.f && p.add == 0.f) ? 1.f : p.mul;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const T* x = (const T*)p.x + i * p.ldx;
+        uint8_t* y = (uint8_t*)p.y + i * p.c;
+        for (int c = 0; c < p.c; ++c) {
+            float v = to_f32<T>(x[c]);
+            if (p.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+            v = fminf(fmaxf(v * mul + p.add, 0.f), 1.f);
+            y[c] = (uint8_t)(v * 255.0f);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void posterior_kernel(const i2i_posterior_params p) {
     const int64_t total = (int64_t)p.n * p.hw;
@@ -96,6 +124,15 @@ extern "C" int i2i_nchw_to_nhwc(const i2i_nchw_to_nhwc_params* p, int dtype, voi
     if (!p || !p->x || !p->y || p->cpad < p->c) return i2i::fail(I2I_ERR_BAD_ARG, "nchw_to_nhwc: bad args");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = grid_for((int64_t)p->n * p->h * p->w);
+    if (p->src_dtype == I2I_U8) {
+        switch (dtype) {
+            case I2I_F32: hipLaunchKernelGGL((u8hwc_to_nhwc_kernel<float>), dim3(g), dim3(256), 0, s, *p); break;
+            case I2I_BF16: hipLaunchKernelGGL((u8hwc_to_nhwc_kernel<__bf16>), dim3(g), dim3(256), 0, s, *p); break;
+            case I2I_F16: hipLaunchKernelGGL((u8hwc_to_nhwc_kernel<_Float16>), dim3(g), dim3(256), 0, s, *p); break;
+            default: return i2i::fail(I2I_ERR_BAD_ARG, "u8hwc_to_nhwc: bad dtype");
+        }
+        return i2i::check_launch("u8hwc_to_nhwc");
+    }
     const bool src_f32 = p->src_dtype == I2I_F32;
     if (!src_f32 && p->src_dtype != dtype) return i2i::fail(I2I_ERR_BAD_ARG, "nchw_to_nhwc: src dtype must be f32 or the compute dtype");
     switch (dtype) {
@@ -117,6 +154,15 @@ extern "C" int i2i_nhwc_to_nchw(const i2i_nhwc_to_nchw_params* p, int dtype, voi
     if (!p || !p->x || !p->y || p->ldx < p->c) return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_nchw: bad args");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = grid_for((int64_t)p->n * p->h * p->w);
+    if (p->dst_dtype == I2I_U8) {
+        switch (dtype) {
+            case I2I_F32: hipLaunchKernelGGL((nhwc_to_u8hwc_kernel<float>), dim3(g), dim3(256), 0, s, *p); break;
+            case I2I_BF16: hipLaunchKernelGGL((nhwc_to_u8hwc_kernel<__bf16>), dim3(g), dim3(256), 0, s, *p); break;
+            case I2I_F16: hipLaunchKernelGGL((nhwc_to_u8hwc_kernel<_Float16>), dim3(g), dim3(256), 0, s, *p); break;
+            default: return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_u8hwc: bad dtype");
+        }
+        return i2i::check_launch("nhwc_to_u8hwc");
+    }
     const bool dst_f32 = p->dst_dtype == I2I_F32;
     if (!dst_f32 && p->dst_dtype != dtype) return i2i::fail(I2I_ERR_BAD_ARG, "nhwc_to_nchw: dst dtype must be f32 or the compute dtype");
     switch (dtype) {

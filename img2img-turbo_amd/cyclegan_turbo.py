@@ -49,7 +49,14 @@ class CycleGAN_Turbo(TurboGeneratorBase):
         self.unet = _XformersShim()
 
     @torch.no_grad()
-    def forward(self, x_t, direction=None, caption=None, caption_emb=None, *, eps=None):
+    def forward_u8(self, images_u8, *args, **kw):
+        """uint8 HWC in/out on the device: ``Normalize([0.5],[0.5])(to_tensor(img))`` (src/inference_unpaired.py:47) and
+        ``ToPILImage()(out*0.5+0.5)`` (:53) run inside the boundary kernels."""
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+        return self.forward(images_u8, *args, _u8_io=(2.0, -1.0), **kw)
+
+    @torch.no_grad()
+    def forward(self, x_t, direction=None, caption=None, caption_emb=None, *, eps=None, _u8_io=None):
         if direction is None:
             assert self.direction is not None
             direction = self.direction
@@ -58,11 +65,15 @@ class CycleGAN_Turbo(TurboGeneratorBase):
             assert self.caption is not None
             caption = self.caption
         caption_enc = caption_emb if caption_emb is not None else self.encode_prompt(caption)
-        B, _, H, W = x_t.shape
+        if _u8_io is not None:
+            B, H, W, _ = x_t.shape
+        else:
+            B, _, H, W = x_t.shape
         lat = self.weights.vae_arch.latent_channels
         if eps is None:
             eps = torch.randn(B, lat, H // 8, W // 8, device=self.device_, dtype=torch.float32)
             torch.randn(B, lat, H // 8, W // 8, device=self.device_, dtype=torch.float32)
         ctx_batch = caption_enc.shape[0] if caption_enc.dim() == 3 else 1
-        plan = self.get_plan(B, H, W, direction=direction, ctx_batch=ctx_batch)
-        return self._execute(plan, x_t, caption_enc, eps).to(x_t.dtype)
+        plan = self.get_plan(B, H, W, direction=direction, ctx_batch=ctx_batch, u8_io=_u8_io)
+        out = self._execute(plan, x_t, caption_enc, eps)
+        return out if _u8_io is not None else out.to(x_t.dtype)

@@ -112,16 +112,19 @@ def attention(q, k, vt, o, *, batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo, q_bs
 
 
 def nchw_to_nhwc(x, y, *, n, c, h, w, cpad, mul=1.0, add=0.0):
+    """x: NCHW float tensor, or a uint8 HWC image batch [n, h, w, c] (then y = x/255*mul + add)."""
     p = K.NchwToNhwcParams()
     p.x, p.y, p.n, p.c, p.h, p.w, p.cpad = ptr(x), ptr(y), n, c, h, w, cpad
-    p.src_dtype, p.mul, p.add = DT[x.dtype], mul, add
+    p.src_dtype, p.mul, p.add = (K.U8 if x.dtype == torch.uint8 else DT[x.dtype]), mul, add
     return K.OP_NCHW_TO_NHWC, p
 
 
-def nhwc_to_nchw(x, y, *, n, c, h, w, ldx, clamp=0):
+def nhwc_to_nchw(x, y, *, n, c, h, w, ldx, clamp=0, mul=0.0, add=0.0):
+    """y: NCHW float tensor, or a uint8 HWC image batch [n, h, w, c] (then y = trunc(clamp01(x*mul+add)*255))."""
     p = K.NhwcToNchwParams()
     p.x, p.y, p.n, p.c, p.h, p.w, p.ldx = ptr(x), ptr(y), n, c, h, w, ldx
-    p.dst_dtype, p.clamp = DT[y.dtype], clamp
+    p.dst_dtype, p.clamp = (K.U8 if y.dtype == torch.uint8 else DT[y.dtype]), clamp
+    p.mul, p.add = mul, add
     return K.OP_NHWC_TO_NCHW, p
 
 

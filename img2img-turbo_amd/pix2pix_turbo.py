@@ -80,13 +80,16 @@ class TurboGeneratorBase(torch.nn.Module):
             self._packers[key] = (self._packers[unet_key], Packer(vae_sd, w.vae_scaling, self.dtype_, self.device_, r))
         return self._packers[key]
 
-    def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1) -> ForwardPlan:
+    def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1, u8_io=None) -> ForwardPlan:
         r_eff = float(r) if stochastic else 1.0
-        key = (B, H, W, self.dtype_, stochastic, round(r_eff, 6), direction, ctx_batch)
+        key = (B, H, W, self.dtype_, stochastic, round(r_eff, 6), direction, ctx_batch, u8_io)
         if key not in self._plans:
+            opts = dict(self.plan_options)
+            if u8_io is not None:
+                opts["u8_io"] = u8_io
             self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
                                            r=r_eff, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
-                                           flash=self.flash, packers=self._get_packers(r_eff, direction), **self.plan_options)
+                                           flash=self.flash, packers=self._get_packers(r_eff, direction), **opts)
         return self._plans[key]
 
     def encode_prompt(self, prompt=None, prompt_tokens=None):
@@ -137,13 +140,23 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
         self.lora_rank_unet, self.lora_rank_vae = lora_rank_unet, lora_rank_vae
 
     @torch.no_grad()
+    def forward_u8(self, images_u8, *args, **kw):
+        """uint8 HWC in, uint8 HWC out ([B, H, W, 3] on the device): the callers' ``F.to_tensor`` (src/inference_paired.py:50)
+        and ``ToPILImage()(out*0.5+0.5)`` (:72) run inside the boundary kernels; everything else as ``forward``."""
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+        return self.forward(images_u8, *args, _u8_io=(1.0, 0.0), **kw)
+
+    @torch.no_grad()
     def forward(self, c_t, prompt=None, prompt_tokens=None, deterministic=True, r=1.0, noise_map=None,
-                *, caption_enc=None, eps=None):
+                *, caption_enc=None, eps=None, _u8_io=None):
         if caption_enc is None:
             # either the prompt or the prompt_tokens should be provided (src/pix2pix_turbo.py:188)
             assert (prompt is None) != (prompt_tokens is None), "Either prompt or prompt_tokens should be provided"
             caption_enc = self.encode_prompt(prompt, prompt_tokens)
-        B, _, H, W = c_t.shape
+        if _u8_io is not None:
+            B, H, W, _ = c_t.shape
+        else:
+            B, _, H, W = c_t.shape
         if not deterministic:
             if noise_map is None:
                 raise ValueError("stochastic forward needs noise_map (src/pix2pix_turbo.py:210)")
@@ -156,8 +169,10 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
             torch.randn(B, lat, H // 8, W // 8, device=self.device_, dtype=torch.float32)
         ctx_batch = caption_enc.shape[0] if caption_enc.dim() == 3 else 1
         assert ctx_batch in (1, B)
-        plan = self.get_plan(B, H, W, stochastic=not deterministic, r=r, ctx_batch=ctx_batch)
+        plan = self.get_plan(B, H, W, stochastic=not deterministic, r=r, ctx_batch=ctx_batch, u8_io=_u8_io)
         out = self._execute(plan, c_t, caption_enc, eps, None if deterministic else noise_map)
+        if _u8_io is not None:
+            return out
         return out.to(c_t.dtype) if c_t.dtype in (torch.float16, torch.bfloat16, torch.float32) else out
 
     def save_model(self, outf):

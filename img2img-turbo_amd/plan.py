@@ -72,7 +72,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         if (H // 8) % 8 or (W // 8) % 8:
             raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
@@ -109,12 +109,17 @@ class ForwardPlan:
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
         # ---- static boundary buffers (graph-stable addresses) ----
-        self.x_in = torch.zeros(B, 3, H, W, dtype=torch.float32, device=device)
+        # u8_io = (mul, add) of the input normalisation: the boundary becomes uint8 HWC image batches on both sides
+        # (row f1: F.to_tensor / Normalize / x*0.5+0.5 / ToPILImage of the callers run inside the boundary kernels)
+        self.u8_io = u8_io
+        self.x_in = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
+                     torch.zeros(B, 3, H, W, dtype=torch.float32, device=device))
         self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
         self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
         self.ctx_batch = ctx_batch
         self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=dtype, device=device)
-        self.out = torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device)
+        self.out = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
+                    torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device))
         self._build()
         self._finish_gn_scratch()
         self.prog.freeze()
@@ -540,7 +545,8 @@ class ForwardPlan:
         h8, w8 = H // 8, W // 8
         self._zero_init = []
         x = self.new(B, H, W, 8)
-        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8), "input.nchw_to_nhwc")
+        mul, add = self.u8_io if self.u8_io else (1.0, 0.0)
+        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8, mul=mul, add=add), "input.to_nhwc")
         moments, skips = self._vae_encoder(x)
         # x (= conv_in input) is not a skip; skips[0] is conv_in's output
         self.free(x)
@@ -560,7 +566,7 @@ class ForwardPlan:
         self.free(e)
         y = self._vae_decoder(z, skips)
         self.free(z)
-        self._add(O.nhwc_to_nchw(y.t, self.out, n=B, c=3, h=H, w=W, ldx=y.c, clamp=1), "output.nhwc_to_nchw")
+        self._add(O.nhwc_to_nchw(y.t, self.out, n=B, c=3, h=H, w=W, ldx=y.c, clamp=1, mul=0.5, add=0.5), "output.from_nhwc")
         for t in self._zero_init:
             t.zero_()
 

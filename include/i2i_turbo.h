@@ -26,7 +26,9 @@ extern "C" {
 
 #define I2I_ABI_VERSION 2
 
-typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2 } i2i_dtype;
+typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
+               I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
+} i2i_dtype;
 
 typedef enum {
     I2I_OK = 0,
@@ -134,12 +136,18 @@ typedef struct {
     int64_t q_bs, k_bs, vt_bs, o_bs; float scale;
 } i2i_attention_params;
 
-/* Boundary layout ops.  NCHW fp32/`dtype` <-> NHWC `dtype` with channel padding (zeros). */
+/* Boundary layout ops.  NCHW fp32/`dtype` <-> NHWC `dtype` with channel padding (zeros).
+ * With src_dtype / dst_dtype = I2I_U8 the outer tensor is a uint8 image batch [n][h][w][c] (HWC, as PIL / numpy hand
+ * it over) and the callers' pre/post-processing is folded in:
+ *   in : y = u8/255 * mul + add     (F.to_tensor, src/inference_paired.py:50; Normalize([0.5],[0.5]) = mul 2, add -1,
+ *                                     src/inference_unpaired.py:47)
+ *   out: u8 = trunc(clamp01(v*mul + add) * 255)   (ToPILImage()(x*0.5+0.5) = mul .5, add .5: src/inference_paired.py:72) */
 typedef struct {
     const void* x; void* y; int32_t n, c, h, w, cpad; int32_t src_dtype; float mul, add;
 } i2i_nchw_to_nhwc_params;
 typedef struct {
     const void* x; void* y; int32_t n, c, h, w, ldx; int32_t dst_dtype; int32_t clamp; /* clamp to [-1,1] */
+    float mul, add;            /* applied after the clamp; 0,0 means 1,0 */
 } i2i_nhwc_to_nchw_params;
 
 /* DiagonalGaussianDistribution.sample() * scaling_factor (+ stochastic mix, src/pix2pix_turbo.py:210):

@@ -335,3 +335,27 @@ def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, 
     err = rel_err(ss.cpu(), ref)
     assert err < 2e-4, f"fused gn stats rel err {err}"
     return err
+
+
+def check_u8_boundary(lib, device, dtype, *, n=2, h=6, w=10, seed=0):
+    """uint8 HWC <-> NHWC with the callers' pre/post-processing folded in (to_tensor / Normalize / x*0.5+0.5 / ToPILImage)."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    y = torch.full((n, h, w, 8), float("nan"), dtype=dtype, device=device)
+    imgd = img.to(device)
+    opcode, p = O.nchw_to_nhwc(imgd, y, n=n, c=3, h=h, w=w, cpad=8, mul=2.0, add=-1.0)
+    run_op(lib, opcode, p, dtype, device)
+    ref = (img.float() / 255.0) * 2.0 - 1.0
+    got = y.cpu().float()
+    assert (got[..., 3:] == 0).all()
+    assert (got[..., :3] - ref.to(dtype).float()).abs().max() <= (1e-6 if dtype == torch.float32 else 8e-3)
+    # output side: values on an exact 1/255 grid survive the round trip bit for bit in fp32
+    x = torch.zeros(n, h, w, 8)
+    x[..., :3] = ref
+    x = x * 1.0
+    xd = x.to(dtype).to(device)
+    out = torch.zeros(n, h, w, 3, dtype=torch.uint8, device=device)
+    opcode, p = O.nhwc_to_nchw(xd, out, n=n, c=3, h=h, w=w, ldx=8, clamp=1, mul=0.5, add=0.5)
+    run_op(lib, opcode, p, dtype, device)
+    exp = ((xd.cpu().float()[..., :3].clamp(-1, 1) * 0.5 + 0.5).clamp(0, 1) * 255.0).to(torch.uint8)
+    assert (out.cpu().int() - exp.int()).abs().max() <= (0 if dtype == torch.float32 else 1)

@@ -58,3 +58,19 @@ def test_pix2pix_halo_everywhere_fp32(emu_lib):
     model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib, plan_options=dict(halo_min_tiles=0))
     out = model(x, caption_enc=cap, eps=eps)
     assert (out - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.slow
+def test_pix2pix_u8_io_matches_float_io(emu_lib):
+    """forward_u8 (uint8 HWC in/out, pre/post-processing inside the boundary kernels) == forward on to_tensor'd input,
+    post-processed the way the reference callers do (src/inference_paired.py:50,72)."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    _, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(1, 64, 64, 1, generator=g) < 0.1).to(torch.uint8).expand(1, 64, 64, 3).contiguous() * 255
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
+    out_f = model(img.permute(0, 3, 1, 2).float() / 255.0, caption_enc=cap, eps=eps)
+    exp = ((out_f * 0.5 + 0.5).clamp(0, 1) * 255.0).to(torch.uint8).permute(0, 2, 3, 1)
+    out_u8 = model.forward_u8(img, caption_enc=cap, eps=eps)
+    assert out_u8.dtype == torch.uint8 and out_u8.shape == (1, 64, 64, 3)
+    assert (out_u8.int() - exp.int()).abs().max() <= 1

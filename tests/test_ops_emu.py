@@ -220,3 +220,8 @@ def test_attention_dma_ring_and_tails(emu_lib, dtype):
 def test_softmax_row_kernel(emu_lib, dtype):
     oc.check_softmax(emu_lib, "cpu", dtype, rows=9, cols=256, ldp=256)        # register-resident path
     oc.check_softmax(emu_lib, "cpu", dtype, rows=5, cols=1024, ldp=1032)      # zero padding past cols
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_u8_boundary(emu_lib, dtype):
+    oc.check_u8_boundary(emu_lib, "cpu", dtype)

@@ -136,3 +136,9 @@ def test_attention_dma_large(gpu_lib, dtype):
 def test_softmax_row_kernel(gpu_lib, dtype):
     oc.check_softmax(gpu_lib, "cuda", dtype, rows=4099, cols=4096, ldp=4096)
     oc.check_softmax(gpu_lib, "cuda", dtype, rows=130, cols=1024, ldp=1032)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_u8_boundary(gpu_lib, dtype):
+    oc.check_u8_boundary(gpu_lib, "cuda", dtype, n=2, h=64, w=48)
