@@ -71,6 +71,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     const int cin = p.c0 + p.c1;
     const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
     const bool gather = p.ks != 1 || p.stride != 1 || p.ups != 0 || p.pad != 0;
+    const int cin_shift = 31 - __builtin_clz((unsigned)(cin > 0 ? cin : 1));     // log2(cin) when cin is a power of two
 
     // ---- K range of this split ----
     const int nk = (p.K + BK - 1) / BK;
@@ -135,6 +136,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             if (pc < PA) {
                 if (!gather) {
                     src = (kok && pc_y[q] >= 0) ? abase + (pc_off[q] * lda_b + pc_chunk[q] * 16u) : zero;
+                } else if (cin < BK) {
+                    // narrow input (VAE conv_in: 3 -> 8 padded channels): a K step spans several taps, so the tap is
+                    // decoded PER CHUNK: k = k0 + chunk*EPC -> tap = k / cin (cin a power of two: host check)
+                    const int k = k0 + (int)pc_chunk[q] * EPC;
+                    const int tp = k >> cin_shift, ci = k & (cin - 1);
+                    const int tky = tp / p.ks, tkx = tp - tky * p.ks;
+                    const int iy = pc_y[q] + tky, ix = pc_x[q] + tkx;
+                    const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
+                    const unsigned pix = pc_off[q] + (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+                    src = ok ? a0 + (pix * ((unsigned)p.lda0 * (unsigned)sizeof(T)) + (unsigned)ci * (unsigned)sizeof(T)) : zero;
                 } else {
                     const int iy = pc_y[q] + ky, ix = pc_x[q] + kx;
                     const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
@@ -455,7 +466,8 @@ bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
     const size_t sz = (dtype == I2I_F32) ? 4 : 2;
     const int cin = p.c0 + p.c1;
     if (p.gn_ss) return false;
-    if (p.ks != 1 && (cin % bk || p.c0 % bk)) return false;
+    const bool narrow = p.ks != 1 && cin < bk && p.c1 == 0 && (cin & (cin - 1)) == 0 && cin >= epc;   // per-chunk tap decode
+    if (p.ks != 1 && !narrow && (cin % bk || p.c0 % bk)) return false;
     if (p.ks == 1 && p.c1 && (p.c0 % bk)) return false;
     if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     if ((p.c_bs_b | p.c_bs_h | p.r_bs_b | p.r_bs_h) & 3) return false;

@@ -225,3 +225,10 @@ def test_softmax_row_kernel(emu_lib, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_u8_boundary(emu_lib, dtype):
     oc.check_u8_boundary(emu_lib, "cpu", dtype)
+
+
+def test_dma_igemm_narrow_input_conv(emu_lib):
+    """VAE conv_in shape class: 3 -> 8 padded input channels, several taps per K step (per-chunk tap decode)."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=3, cout=40, h=9, w=12, tile=20)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=4, cout=32, h=6, w=7, tile=20)        # latent conv_in (4 -> 8 padded)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=16, cout=24, h=5, w=5, stride=2, pad=1, tile=22)
