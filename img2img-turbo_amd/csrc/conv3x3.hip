@@ -575,6 +575,7 @@ int halo_cfg(const i2i_igemm_params& p) {
         if (p.N <= 16) cfg = 16;
         else if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64)) cfg = tall ? 14 : 15;
         else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles_bench_ops.log)
+        else if (p.N == 256 && p.c0 + p.c1 == 256 && p.ho * p.wo >= 128 * 128) cfg = 34;   // +6 % (profiles/r1_conv_bn256_bench_ops.log)
         else cfg = (p.c0 + p.c1 <= 256) ? 17 : 13;
     }
     return cfg;
@@ -586,6 +587,7 @@ void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
         case 12: case 18: case 32: *th = 16; *bn = 128; *wtn = 64; break;
         case 13: case 17: case 31: case 33: *th = 8; *bn = 128; *wtn = 64; break;
         case 14: *th = 16; *bn = 64; *wtn = 32; break;
+        case 34: *th = 8; *bn = 256; *wtn = 64; break;
         case 15: *th = 8; *bn = 64; *wtn = 32; break;
         default: *th = 8; *bn = 16; *wtn = 16; break;
     }
@@ -609,6 +611,7 @@ int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
         case 17: return launch_halo<T, 8, 128, 2, 2, 3, 2>(p, s);    // as 13, prefetch distance 3
         case 18: return launch_halo<T, 16, 128, 4, 2, 3, 2>(p, s);   // as 12, prefetch distance 3
         case 19: return launch_halo<T, 16, 128, 2, 2, 3, 1>(p, s);   // as 11, prefetch distance 3
+        case 34: return launch_halo<T, 8, 256, 2, 4, 2, 2>(p, s);    // 8 waves x (4 rows x 64 ch): halo staged once per 256 channels
         case 31: return launch_halo<T, 8, 128, 2, 2, 2, 2, false, true>(p, s);    // as 13, double-buffered halo + 2-deep ring
         case 32: return launch_halo<T, 16, 128, 4, 2, 2, 2, false, true>(p, s);   // as 12, double-buffered halo
         case 33: return launch_halo<T, 8, 128, 2, 2, 3, 2, false, true>(p, s);    // as 31, prefetch distance 3

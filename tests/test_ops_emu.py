@@ -120,7 +120,7 @@ def test_halo_conv_upsample_concat_smallN(emu_lib):
     oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=64, cout=3, h=8, w=16, gn=True, act=1, groups=8, tile=10)   # conv_out (BN=16)
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33, 34])
 def test_halo_conv_every_tile_config(emu_lib, cfg):
     """Each conv3x3.hip tile configuration forced by id: ragged plane (partial tiles both ways), two slabs
     (register-parked halo hand-over), GN+SiLU prologue, residual, N not a multiple of the channel tile."""

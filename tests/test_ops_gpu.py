@@ -75,7 +75,7 @@ def test_halo_conv(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33, 34])
 def test_halo_conv_every_tile_config(gpu_lib, cfg):
     """Every conv3x3.hip tile configuration on the real LDS-DMA path (the emulator copies synchronously, so
     only the GPU run can see a missing wait): ragged planes, 2-4 slabs, GN+SiLU, residual, concat, upsample."""
