@@ -28,7 +28,7 @@ class IgemmParams(C.Structure):
                 ("res", vp), ("ldr", i32), ("r_bs_b", i64), ("r_bs_h", i64),
                 ("c", vp), ("ldc", i32), ("c_bs_b", i64), ("c_bs_h", i64),
                 ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32),
-                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32)]
+                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32), ("up_h", i32), ("up_w", i32)]
 
 
 class GnStatsParams(C.Structure):

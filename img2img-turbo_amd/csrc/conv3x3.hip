@@ -92,7 +92,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     const T* __restrict__ a1 = (const T*)p.a1;
     const T* __restrict__ bw = (const T*)p.b + (SUBPIX ? (int64_t)(pa * 2 + pb) * p.N * p.ldb : 0);
     const int cin = p.c0 + p.c1;
-    const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
+    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
     const bool has_gn = p.gn_ss != nullptr;
 
     // LDS map.  DBH: weights first (so the buffer toggle is an XOR of the offset with BN*128), two halo images, two
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             } else {
                 const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;       // coordinates in the (upsampled) input plane
                 if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up)
-                    pix = (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+                    pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
             }
         }
         hpix[j] = pix;
@@ -628,7 +628,8 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2) return false;
     if (p.c0 % ck || p.c1 % ck || (p.c0 + p.c1) < ck) return false;
     if (p.wo < TW || p.ho < 8) return false;
-    if (p.ho != (p.hin << p.ups) || p.wo != (p.win << p.ups)) return false;
+    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
+    if ((p.up_h || p.up_w) && (p.ups != 1 || p.subpix)) return false;
     if (p.subpix && (p.ups != 1 || p.win < TW || p.hin < 8 || p.ldb != 4 * (p.c0 + p.c1) || p.gn_part)) return false;
     if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     return true;

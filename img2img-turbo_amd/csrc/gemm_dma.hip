@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     const char* bw = (const char*)((const T*)p.b + (int64_t)zb * p.b_bs_b + (int64_t)zh * p.b_bs_h);
     const char* zero = (const char*)g_zero16;
     const int cin = p.c0 + p.c1;
-    const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
+    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
     const bool gather = p.ks != 1 || p.stride != 1 || p.ups != 0 || p.pad != 0;
     const int cin_shift = 31 - __builtin_clz((unsigned)(cin > 0 ? cin : 1));     // log2(cin) when cin is a power of two
 
@@ -144,12 +144,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                     const int tky = tp / p.ks, tkx = tp - tky * p.ks;
                     const int iy = pc_y[q] + tky, ix = pc_x[q] + tkx;
                     const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
-                    const unsigned pix = pc_off[q] + (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+                    const unsigned pix = pc_off[q] + (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
                     src = ok ? a0 + (pix * ((unsigned)p.lda0 * (unsigned)sizeof(T)) + (unsigned)ci * (unsigned)sizeof(T)) : zero;
                 } else {
                     const int iy = pc_y[q] + ky, ix = pc_x[q] + kx;
                     const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
-                    const unsigned pix = pc_off[q] + (unsigned)((iy >> p.ups) * p.win + (ix >> p.ups));
+                    const unsigned pix = pc_off[q] + (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
                     src = ok ? abase + (pix * lda_b + pc_chunk[q] * 16u) : zero;
                 }
             } else {

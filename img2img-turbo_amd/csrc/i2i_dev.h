@@ -92,6 +92,14 @@ __device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 128
 __device__ __forceinline__ int lds_swz2(int row) { return ((row >> 1) & 3) << 1; }
 __device__ __forceinline__ int lds_chunk_off2(int row, int kc) { return row * 128 + ((kc ^ lds_swz2(row)) << 4); }
 
+// Nearest-neighbour source index of upsampled coordinate i (F.interpolate(mode="nearest")): exact 2x is a shift; an
+// explicit output size `up` != 2*in uses ATen's rule min(floor(i * (float)in/up), in-1).
+__device__ __forceinline__ int up_src(int i, int in, int up, int ups) {
+    if (up == (in << ups)) return i >> ups;
+    const int j = (int)floorf((float)i * ((float)in / (float)up));
+    return j < in - 1 ? j : in - 1;
+}
+
 // ---- explicit synchronisation for LDS-DMA pipelines (cdna_hip_programming.md section 5: raw s_barrier +
 // counted waits; __syncthreads() would drain the DMA queue with vmcnt(0) at every barrier).
 // The CPU emulator (tests/emu, I2I_EMU) executes copies synchronously, so the waits are no-ops there.

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const i2i_igemm_para
     // ---- per-thread A rows (fixed for the whole K loop) ----
     const int kc = tid & 7;
     const int cin = p.c0 + p.c1;
-    const int hin_up = p.hin << p.ups, win_up = p.win << p.ups;
+    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
     int a_img[APT], a_iy0[APT], a_ix0[APT];
     {
         const int hw = p.ho * p.wo;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const i2i_igemm_para
             const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
             const bool ok = kvalid && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
             if (ok) {
-                const int64_t off = ((int64_t)(a_img[i] * p.hin + (iy >> p.ups)) * p.win + (ix >> p.ups)) * ld + cc;
+                const int64_t off = ((int64_t)(a_img[i] * p.hin + up_src(iy, p.hin, hin_up, p.ups)) * p.win + up_src(ix, p.win, win_up, p.ups)) * ld + cc;
                 ra[i] = *(const chunk_t*)(src + off);
                 amask |= 1u << i;
             } else {

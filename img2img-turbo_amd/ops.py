@@ -17,7 +17,7 @@ def ptr(t):
 
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
-         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0):
+         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None):
     """Implicit-GEMM conv / linear over NHWC sources.  ``w`` is packed [N][ks*ks*(c0+c1)]."""
     p = K.IgemmParams()
     c0 = x0.shape[-1] if c0 is None else c0
@@ -43,6 +43,7 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.zcount, p.zh_count = 1, 1
     p.geglu, p.out_f32, p.tile = geglu, out_f32, tile
     p.splitk, p.ws, p.subpix = splitk, ptr(ws), subpix
+    p.up_h, p.up_w = up_size if up_size else (0, 0)
     return K.OP_IGEMM, p
 
 

@@ -74,9 +74,8 @@ class ForwardPlan:
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
                  ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
-        if (H // 8) % 8 or (W // 8) % 8:
-            raise NotImplementedError("H and W must be multiples of 64: odd latent sizes need the UNet's explicit "
-                                      "upsample sizes (DESIGN.md row f3, not built yet)")
+        # H, W multiples of 8 suffice (src/inference_paired.py:38-41): latent sizes that are not multiples of 8 make the
+        # UNet levels odd (70 -> 35 -> 18 -> 9), handled like diffusers' forward_upsample_size path (explicit sizes).
         self.lib, self.w8s, self.B, self.H, self.W = lib, weights, B, H, W
         self.dtype, self.device = dtype, device
         self.dt = O.DT[dtype]
@@ -200,22 +199,24 @@ class ForwardPlan:
             return 0, None
         return sk, self.pool.get(sk * M * N, torch.float32)
 
-    def upsample_conv(self, pk, name, x: Act, label) -> Act:
+    def upsample_conv(self, pk, name, x: Act, label, size=None) -> Act:
         """Upsample2D: nearest-2x + 3x3 conv.  Sub-pixel form (4/9 of the MACs, csrc/conv3x3.hip SUBPIX) whenever the
         halo kernel takes it -- slab-aligned channels, source plane of at least one 8x16 tile; else the index-map gather."""
         bk = 32 if self.dtype == torch.float32 else 64
-        if self.subpix and x.c % bk == 0 and x.h >= 8 and x.w >= 16:
+        if size is not None and tuple(size) == (2 * x.h, 2 * x.w):
+            size = None
+        if size is None and self.subpix and x.c % bk == 0 and x.h >= 8 and x.w >= 16:
             return self.conv(pk.conv_subpixel(name), x, ups=1, label=label)
-        return self.conv(pk.conv(name), x, ups=1, label=label)
+        return self.conv(pk.conv(name), x, ups=1, up_size=size, label=label)   # explicit size: F.interpolate(size=...)
 
-    def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, asym=False, x1: Optional[Act] = None, gn=False, act=0,
+    def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, up_size=None, asym=False, x1: Optional[Act] = None, gn=False, act=0,
              res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
              label="") -> Act:
         """One implicit-GEMM launch.  ``gn``: apply the pending GroupNorm scale/shift (+act) to the A operand."""
         ks = ks or pw["ks"]
         pad = (ks // 2 if not asym else 0) if pad is None else pad
         hin, win = x.h, x.w
-        hu, wu = hin << ups, win << ups
+        hu, wu = up_size if up_size else (hin << ups, win << ups)
         if asym:           # F.pad(0,1,0,1) + stride-2 p0 (VAE Downsample2D)
             ho, wo = (hu + 1 - ks) // stride + 1, (wu + 1 - ks) // stride + 1
         else:
@@ -260,7 +261,7 @@ class ForwardPlan:
                     x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
                     gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
                     res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
-                    splitk=splitk, ws=ws, subpix=subpix, tile=force_tile)
+                    splitk=splitk, ws=ws, subpix=subpix, tile=force_tile, up_size=up_size)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
         out.producer = op[1]
@@ -321,21 +322,25 @@ class ForwardPlan:
         self._add(op, prefix + ".gn_apply")
         qk = self.linear(pk.stacked_linear([prefix + ".to_q", prefix + ".to_k"]), xn.t, B * T, C, label=prefix + ".to_qk")
         wv = pk.conv(prefix + ".to_v")
-        vt = self.pool.get(B * C * T, self.dtype)
-        self._add(O.bgemm(wv["w"], xn.t, vt, M=C, N=T, Kdim=C, lda=C, ldb=C, ldc=T, batch=B, heads=1, a_bs=(0, 0),
-                          b_bs=(T * C, 0), c_bs=(C * T, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T")
+        Tp = (T + 7) // 8 * 8                      # row pitch of V^T / scores / probabilities (T itself when the plane is /8-aligned)
+        vt = self.pool.get(B * C * Tp, self.dtype)
+        self._add(O.bgemm(wv["w"], xn.t, vt, M=C, N=T, Kdim=C, lda=C, ldb=C, ldc=Tp, batch=B, heads=1, a_bs=(0, 0),
+                          b_bs=(T * C, 0), c_bs=(C * Tp, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T")
         self.flops += 2 * B * T * C * C
         self.free(xn)
-        s = self.pool.get(B * T * T, torch.float32)
-        self._add(O.bgemm(qk, qk[C:], s, M=T, N=T, Kdim=C, lda=2 * C, ldb=2 * C, ldc=T, batch=B, heads=1,
-                          a_bs=(T * 2 * C, 0), b_bs=(T * 2 * C, 0), c_bs=(T * T, 0), out_f32=1), prefix + ".qk^T")
-        p = self.pool.get(B * T * T, self.dtype)
-        self._add(O.softmax(s, p, rows=B * T, cols=T, lds=T, ldp=T, scale=1.0 / math.sqrt(C)), prefix + ".softmax")
+        s = self.pool.get(B * T * Tp, torch.float32)
+        self._add(O.bgemm(qk, qk[C:], s, M=T, N=T, Kdim=C, lda=2 * C, ldb=2 * C, ldc=Tp, batch=B, heads=1,
+                          a_bs=(T * 2 * C, 0), b_bs=(T * 2 * C, 0), c_bs=(T * Tp, 0), out_f32=1), prefix + ".qk^T")
+        p = self.pool.get(B * T * Tp, self.dtype)
+        self._add(O.softmax(s, p, rows=B * T, cols=T, lds=Tp, ldp=Tp, scale=1.0 / math.sqrt(C)), prefix + ".softmax")
         self.pool.put(s)
         self.pool.put(qk)
         o = self.pool.get(B * T * C, self.dtype)
-        self._add(O.bgemm(p, vt, o, M=T, N=C, Kdim=T, lda=T, ldb=T, ldc=C, batch=B, heads=1, a_bs=(T * T, 0), b_bs=(C * T, 0),
+        # pad columns of P are exact zeros; the matching V^T columns only have to be finite (zeroed once below)
+        self._add(O.bgemm(p, vt, o, M=T, N=C, Kdim=Tp, lda=Tp, ldb=Tp, ldc=C, batch=B, heads=1, a_bs=(T * Tp, 0), b_bs=(C * Tp, 0),
                           c_bs=(T * C, 0)), prefix + ".pv")
+        if Tp != T:
+            self._zero_init.append(vt)
         self.flops += 4 * B * T * T * C
         self.pool.put(p)
         self.pool.put(vt)
@@ -501,7 +506,8 @@ class ForwardPlan:
                     h2 = h3
                 h = h2
             if i < nb - 1:
-                h2 = self.upsample_conv(pk, f"up_blocks.{i}.upsamplers.0.conv", h, f"up_blocks.{i}.upsamplers.0.conv")
+                nxt = res[-1]      # the next level's skip fixes the output size (UNet2DConditionModel.forward: upsample_size)
+                h2 = self.upsample_conv(pk, f"up_blocks.{i}.upsamplers.0.conv", h, f"up_blocks.{i}.upsamplers.0.conv", size=(nxt.h, nxt.w))
                 self.free(h)
                 h = h2
         assert not res

@@ -61,7 +61,7 @@ typedef enum {
  * load (W' = W + s.B.A), so one launch covers base + adapter.
  *
  * A operand: virtual concat of up to two NHWC sources [nimg][hin][win][c0 | c1]; m -> (img, oy, ox),
- *            k -> (ky, kx, ci); input coord = (o*stride + k - pad) >> ups, zero outside.
+ *            k -> (ky, kx, ci); input coord = up_map(o*stride + k - pad) (>> ups, or the explicit up_h/up_w map), zero outside.
  *            z (grid z) adds zb*a_bs_b + zh*a_bs_h with zb = z / zh_count, zh = z % zh_count.
  * B operand: [N][ldb] k-contiguous (weights, or K of q.k^T, or V^T of p.v).
  * ------------------------------------------------------------------------------------------- */
@@ -95,6 +95,9 @@ typedef struct {
     int32_t subpix;            /* 1 (with ups = 1, ks = 3, stride 1, pad 1): `b` holds the SUB-PIXEL form of the
                                   upsample+conv, [4 parities (a,b)][N][2*2*cin] with ldb = 4*cin, tap weights
                                   pre-summed per output parity (packer.subpixel_weights); K stays 9*cin */
+    int32_t up_h, up_w;        /* ups = 1 only: explicit size of the nearest-upsampled plane (F.interpolate(size=...), the
+                                  UNet's forward_upsample_size path for latent sizes that are not multiples of 8);
+                                  0,0 = (2*hin, 2*win).  Source index = min(floor(i * in/up), in-1) as ATen computes it */
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.

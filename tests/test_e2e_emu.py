@@ -74,3 +74,16 @@ def test_pix2pix_u8_io_matches_float_io(emu_lib):
     out_u8 = model.forward_u8(img, caption_enc=cap, eps=eps)
     assert out_u8.dtype == torch.uint8 and out_u8.shape == (1, 64, 64, 3)
     assert (out_u8.int() - exp.int()).abs().max() <= 1
+
+
+@pytest.mark.slow
+def test_pix2pix_odd_latent_size_fp32(emu_lib):
+    """72 x 88 input (multiples of 8, not of 64): latent 9 x 11, UNet levels 9x11 -> 5x6 -> 3x3 -> 2x2 with explicit
+    upsample sizes (row f3; the reference resizes to multiples of 8 only: src/inference_paired.py:38-41)."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 1, 72, 88, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
+    out = model(x, caption_enc=cap, eps=eps)
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 1e-3

@@ -92,6 +92,37 @@ def test_tiny_cyclegan(gpu_lib, direction):
     assert report(f"tiny cyclegan {direction}", out, ref) < 1e-3
 
 
+def test_tiny_odd_sizes_and_u8_io(gpu_lib):
+    """Rows f3 / f1: an input whose latent size is not a multiple of 8 (explicit UNet upsample sizes, ragged tiles
+    everywhere) and the uint8 HWC boundary."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 2, 72, 88, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    assert report("tiny 72x88 fp32", out, ref) < 1e-3
+    img = (x.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
+    out_u8 = model.forward_u8(img.cuda(), caption_enc=cap.cuda(), eps=eps.cuda()).cpu()
+    exp = ((ref * 0.5 + 0.5).clamp(0, 1) * 255.0).to(torch.uint8).permute(0, 2, 3, 1)
+    assert (out_u8.int() - exp.int()).abs().max() <= 1
+
+
+def test_sd_turbo_odd_size_264x328(gpu_lib):
+    """Real architecture at a size the reference accepts but /64 tilings do not: latent 33 x 41, UNet levels
+    33x41 -> 17x21 -> 9x11 -> 5x6, upsampled back with explicit sizes."""
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 1)
+    x, cap, eps, _ = make_inputs("canny", 1, 264, 328, SD_TURBO_UNET.cross_attention_dim, seed=1)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    assert report("SD-Turbo 264x328 fp32", out, ref) < 1e-3
+    del model
+    torch.cuda.empty_cache()
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    assert report("SD-Turbo 264x328 bf16", out, ref) < TOL[torch.bfloat16]
+
+
 def test_full_sd_turbo_512(gpu_lib):
     """BASELINE config 1 vs GPU: the real SD-Turbo architecture (866M-param UNet, 84M VAE, LoRA r8/r4), one
     512x512 image, CPU oracle fp32 vs exact-f32 MFMA (<= 1e-3) and vs bf16 (measured)."""

@@ -232,3 +232,34 @@ def test_dma_igemm_narrow_input_conv(emu_lib):
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=3, cout=40, h=9, w=12, tile=20)
     oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=4, cout=32, h=6, w=7, tile=20)        # latent conv_in (4 -> 8 padded)
     oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=16, cout=24, h=5, w=5, stride=2, pad=1, tile=22)
+
+
+def test_conv_explicit_upsample_size(emu_lib):
+    """F.interpolate(size=...) with a size that is not 2x (UNet forward_upsample_size path, odd latent sizes): the
+    gather kernels use ATen's nearest rule min(floor(i*in/out), in-1)."""
+    import torch.nn.functional as F
+    from img2img_turbo_amd import ops as O
+    g = torch.Generator().manual_seed(0)
+    for dtype, cin, tile in ((torch.float32, 32, 20), (torch.bfloat16, 64, 0), (torch.float32, 8, 1)):
+        n, h, w, cout, uh, uw = 2, 9, 5, 24, 17, 9
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        xq, wq = x.to(dtype).float(), wt.to(dtype).float()
+        ref = F.conv2d(F.interpolate(xq, size=(uh, uw), mode="nearest"), wq, b, padding=1)
+        x0 = oc.nhwc(x, dtype)
+        wp = oc.pack_conv_weight(wt, dtype)
+        out = torch.full((n, uh, uw, cout), float("nan"), dtype=dtype)
+        opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=uh, wo=uw, ks=3, stride=1, pad=1, ups=1, N=cout, bias=b, tile=tile, up_size=(uh, uw))
+        oc.run_op(emu_lib, opcode, p, dtype, "cpu")
+        got = out.float().permute(0, 3, 1, 2)
+        assert oc.rel_err(got, ref) < oc.TOL[dtype]
+    # halo kernel with an explicit size (wide enough plane)
+    n, cin, cout, h, w, uh, uw = 1, 64, 32, 9, 9, 17, 18
+    x = torch.randn(n, cin, h, w, generator=g); wt = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    ref = F.conv2d(F.interpolate(x.to(torch.bfloat16).float(), size=(uh, uw), mode="nearest"), wt.to(torch.bfloat16).float(), None, padding=1)
+    out = torch.full((n, uh, uw, cout), float("nan"), dtype=torch.bfloat16)
+    opcode, p = O.conv(oc.nhwc(x, torch.bfloat16), oc.pack_conv_weight(wt, torch.bfloat16), out, nimg=n, hin=h, win=w, ho=uh, wo=uw, ks=3,
+                       stride=1, pad=1, ups=1, N=cout, tile=10, up_size=(uh, uw))
+    oc.run_op(emu_lib, opcode, p, torch.bfloat16, "cpu")
+    assert oc.rel_err(out.float().permute(0, 3, 1, 2), ref) < oc.TOL[torch.bfloat16]
