@@ -15,6 +15,13 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _keep(p, *tensors):
+    """The descriptors carry raw pointers only; pin the tensors to the descriptor so a temporary passed by a caller
+    cannot be freed while a program still references it."""
+    p._keep = tuple(t for t in tensors if t is not None)
+    return p
+
+
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
          res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None):
@@ -44,7 +51,7 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.geglu, p.out_f32, p.tile = geglu, out_f32, tile
     p.splitk, p.ws, p.subpix = splitk, ptr(ws), subpix
     p.up_h, p.up_w = up_size if up_size else (0, 0)
-    return K.OP_IGEMM, p
+    return K.OP_IGEMM, _keep(p, x0, x1, w, out, gn_ss, bias, res, ws)
 
 
 def bgemm(a, b, out, *, M, N, Kdim, lda, ldb, ldc, batch, heads, a_bs, b_bs, c_bs, alpha=1.0, out_f32=0,
@@ -64,7 +71,7 @@ def bgemm(a, b, out, *, M, N, Kdim, lda, ldb, ldc, batch, heads, a_bs, b_bs, c_b
     p.c_bs_b, p.c_bs_h = c_bs
     p.zcount, p.zh_count = batch * heads, heads
     p.out_f32, p.tile = out_f32, tile
-    return K.OP_IGEMM, p
+    return K.OP_IGEMM, _keep(p, a, b, out, bias)
 
 
 def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=None, c0=None, c1=0,

@@ -259,7 +259,8 @@ def test_conv_explicit_upsample_size(emu_lib):
     x = torch.randn(n, cin, h, w, generator=g); wt = torch.randn(cout, cin, 3, 3, generator=g) / 24
     ref = F.conv2d(F.interpolate(x.to(torch.bfloat16).float(), size=(uh, uw), mode="nearest"), wt.to(torch.bfloat16).float(), None, padding=1)
     out = torch.full((n, uh, uw, cout), float("nan"), dtype=torch.bfloat16)
-    opcode, p = O.conv(oc.nhwc(x, torch.bfloat16), oc.pack_conv_weight(wt, torch.bfloat16), out, nimg=n, hin=h, win=w, ho=uh, wo=uw, ks=3,
+    x0, wp = oc.nhwc(x, torch.bfloat16), oc.pack_conv_weight(wt, torch.bfloat16)     # keep alive: ops hold raw pointers
+    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=uh, wo=uw, ks=3,
                        stride=1, pad=1, ups=1, N=cout, tile=10, up_size=(uh, uw))
     oc.run_op(emu_lib, opcode, p, torch.bfloat16, "cpu")
     assert oc.rel_err(out.float().permute(0, 3, 1, 2), ref) < oc.TOL[torch.bfloat16]
