@@ -13,7 +13,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libi2i_turbo.so")
 
 F32, BF16, F16, U8 = 0, 1, 2, 3
 OP_IGEMM, OP_GN_STATS, OP_LAYERNORM, OP_SOFTMAX = 1, 2, 3, 4
-OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY = 5, 6, 7, 8, 9, 10
+OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY, OP_EMBED = 5, 6, 7, 8, 9, 10, 11
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -28,7 +28,7 @@ class IgemmParams(C.Structure):
                 ("res", vp), ("ldr", i32), ("r_bs_b", i64), ("r_bs_h", i64),
                 ("c", vp), ("ldc", i32), ("c_bs_b", i64), ("c_bs_h", i64),
                 ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32),
-                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32), ("up_h", i32), ("up_w", i32)]
+                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32), ("act_out", i32), ("up_h", i32), ("up_w", i32)]
 
 
 class GnStatsParams(C.Structure):
@@ -55,7 +55,11 @@ class AttentionParams(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
                 ("batch", i32), ("heads", i32), ("d", i32), ("tq", i32), ("tk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldvt", i32), ("ldo", i32),
-                ("q_bs", i64), ("k_bs", i64), ("vt_bs", i64), ("o_bs", i64), ("scale", f32)]
+                ("q_bs", i64), ("k_bs", i64), ("vt_bs", i64), ("o_bs", i64), ("scale", f32), ("causal", i32)]
+
+
+class EmbedParams(C.Structure):
+    _fields_ = [("ids", vp), ("tok", vp), ("pos", vp), ("y", vp), ("rows", i32), ("T", i32), ("c", i32), ("vocab", i32)]
 
 
 class NchwToNhwcParams(C.Structure):
@@ -83,7 +87,7 @@ class DdpmParams(C.Structure):
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmParams), ("gn_stats", GnStatsParams), ("gn_apply", GnApplyParams),
                 ("layernorm", LayerNormParams), ("softmax", SoftmaxParams), ("attention", AttentionParams),
-                ("to_nhwc", NchwToNhwcParams), ("to_nchw", NhwcToNchwParams),
+                ("to_nhwc", NchwToNhwcParams), ("to_nchw", NhwcToNchwParams), ("embed", EmbedParams),
                 ("posterior", PosteriorParams), ("ddpm", DdpmParams)]
 
 
@@ -93,11 +97,11 @@ class Op(C.Structure):
 
 _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply", OP_LAYERNORM: "layernorm",
              OP_SOFTMAX: "softmax", OP_ATTENTION: "attention", OP_NCHW_TO_NHWC: "to_nhwc",
-             OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm"}
+             OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed"}
 
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
-           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_run", "i2i_run_timed",
+           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
 
 
@@ -150,7 +154,7 @@ class Library:
         L.i2i_last_error.restype = C.c_char_p
         L.i2i_sizeof_op.restype = C.c_size_t
         for name in ("i2i_igemm", "i2i_gn_stats", "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention",
-                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant"):
+                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed"):
             getattr(L, name).argtypes = [vp, C.c_int, vp]
             getattr(L, name).restype = C.c_int
         L.i2i_igemm_gn_parts.argtypes = [vp, C.c_int, C.c_int]

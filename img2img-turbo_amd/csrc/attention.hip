@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const i2i_attention_para
             for (int r = 0; r < 4; ++r) {
                 const int key = kv0 + kf * 16 + lq * 4 + r;
                 float s = sacc[kf][r] * p.scale;
-                if (key >= p.tk) s = -1e30f;
+                if (key >= p.tk || (p.causal && key > q0 + lr)) s = -1e30f;
                 sacc[kf][r] = s;
                 mt = fmaxf(mt, s);
             }
@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float sv = sacc[f][kf][r] * c2;
-                    if (tail && kv0 + kf * 16 + lq * 4 + r >= p.tk) sv = -1e30f;
+                    const int key = kv0 + kf * 16 + lq * 4 + r;
+                    if ((tail && key >= p.tk) || (p.causal && key > q0 + f * 16 + lr)) sv = -1e30f;
                     sacc[f][kf][r] = sv;
                     mt = fmaxf(mt, sv);
                 }
@@ -381,6 +382,7 @@ extern "C" int i2i_attention(const i2i_attention_params* p, int dtype, void* str
     if (p->ldq % epc || p->ldk % epc || p->ldvt % epc || p->ldo % 4 || p->tk < 1 || p->tq < 1)
         return i2i::fail(I2I_ERR_BAD_ARG, "attention: bad leading dims");
     if (p->ldvt < ((p->tk + epc - 1) / epc) * epc) return i2i::fail(I2I_ERR_BAD_ARG, "attention: ldvt must cover tk rounded up to a chunk");
+    if (p->causal && p->tq != p->tk) return i2i::fail(I2I_ERR_BAD_ARG, "attention: causal needs tq == tk");
     hipStream_t s = (hipStream_t)stream;
     // 16-bit types: LDS-DMA kernel (needs 8-byte aligned output rows for its vector stores); f32 parity mode: the
     // register-staged kernel

@@ -61,6 +61,26 @@ __global__ __launch_bounds__(256) void nhwc_to_u8hwc_kernel(const i2i_nhwc_to_nc
     }
 }
 
+// CLIP text embeddings: one 8-element unit per thread, y = tok[ids[row]] + pos[row % T] (sum in fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const i2i_embed_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int upr = p.c / EPC;
+    const int64_t total = (int64_t)p.rows * upr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / upr), u = (int)(i - (int64_t)row * upr);
+        int64_t id = p.ids[row];
+        id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
+        const chunk_t a = *(const chunk_t*)((const T*)p.tok + id * p.c + u * EPC);
+        const chunk_t b = *(const chunk_t*)((const T*)p.pos + (int64_t)(row % p.T) * p.c + u * EPC);
+        chunk_t o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32<T>(a[e]) + to_f32<T>(b[e]));
+        *(chunk_t*)((T*)p.y + (int64_t)row * p.c + u * EPC) = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void posterior_kernel(const i2i_posterior_params p) {
     const int64_t total = (int64_t)p.n * p.hw;
@@ -206,4 +226,17 @@ extern "C" int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* str
         default: return i2i::fail(I2I_ERR_BAD_ARG, "ddpm: bad dtype");
     }
     return i2i::check_launch("ddpm");
+}
+
+extern "C" int i2i_embed(const i2i_embed_params* p, int dtype, void* stream) {
+    if (!p || !p->ids || !p->tok || !p->pos || !p->y || p->c % 8 || p->T < 1 || p->vocab < 1) return i2i::fail(I2I_ERR_BAD_ARG, "embed: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for((int64_t)p->rows * (p->c / 4));
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((embed_kernel<float>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_BF16: hipLaunchKernelGGL((embed_kernel<__bf16>), dim3(g), dim3(256), 0, s, *p); break;
+        case I2I_F16: hipLaunchKernelGGL((embed_kernel<_Float16>), dim3(g), dim3(256), 0, s, *p); break;
+        default: return i2i::fail(I2I_ERR_BAD_ARG, "embed: bad dtype");
+    }
+    return i2i::check_launch("embed");
 }

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                     if (m >= p.M || n >= p.N) continue;
                     const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r] + bm;
+                    for (int r = 0; r < 8; ++r) v[r] = act_out_f(p.alpha * v[r] + bv[r] + bm, p.act_out);
                     if (res) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][jp][r]);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r] + bm;
+            for (int r = 0; r < 4; ++r) v[r] = act_out_f(p.alpha * acc[i][j][r] + bv[r] + bm, p.act_out);
             if (n + 3 < p.N) {
                 if (res) {
                     const tx4 rv = *(const tx4*)(res + (int64_t)m * p.ldr + n);
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const i2i_igemm_para
         float t = p.alpha * v[r];
         if (p.bias_mode == 1) t += p.bias[n];
         else if (p.bias_mode == 2) t += p.bias[m];
+        t = act_out_f(t, p.act_out);
         if (p.res) t += to_f32<T>(((const T*)p.res)[(int64_t)m * p.ldr + n]);
         if (p.out_f32) ((float*)p.c)[(int64_t)m * p.ldc + n] = t;
         else ((T*)p.c)[(int64_t)m * p.ldc + n] = from_f32<T>(t);
@@ -477,6 +478,7 @@ bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
     const uint64_t b_bytes = (uint64_t)p.N * p.ldb * sz;
     if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
     if (p.splitk > 1 && (!p.ws || p.zcount > 1 || p.geglu)) return false;
+    if (p.act_out && p.geglu) return false;
     return true;
 }
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s) {

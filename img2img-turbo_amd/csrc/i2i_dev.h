@@ -92,6 +92,13 @@ __device__ __forceinline__ int lds_chunk_off(int row, int kc) { return row * 128
 __device__ __forceinline__ int lds_swz2(int row) { return ((row >> 1) & 3) << 1; }
 __device__ __forceinline__ int lds_chunk_off2(int row, int kc) { return row * 128 + ((kc ^ lds_swz2(row)) << 4); }
 
+// epilogue activation selector (i2i_igemm_params.act_out): 1 GELU (erf form), 2 quick_gelu
+__device__ __forceinline__ float act_out_f(float x, int kind) {
+    if (kind == 1) return gelu_erf_f(x);
+    if (kind == 2) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    return x;
+}
+
 // Nearest-neighbour source index of upsampled coordinate i (F.interpolate(mode="nearest")): exact 2x is a shift; an
 // explicit output size `up` != 2*in uses ATen's rule min(floor(i * (float)in/up), in-1).
 __device__ __forceinline__ int up_src(int i, int in, int up, int ups) {

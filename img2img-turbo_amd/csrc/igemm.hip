@@ -299,6 +299,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
     if (p.gn_part && !i2i::conv3x3_halo_gn_parts(p, dtype, p.gn_part_groups))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: gn_part requested but this op cannot produce GroupNorm partials (query i2i_igemm_gn_parts first)");
+    if (p.act_out && (!i2i::igemm_dma_eligible(p, dtype) || i2i::conv3x3_halo_eligible(p, dtype)))
+        return i2i::fail(I2I_ERR_BAD_ARG, "igemm: act_out is implemented by the LDS-DMA igemm only (no GN prologue, aligned output, not a halo conv)");
     if (p.subpix && !i2i::conv3x3_halo_eligible(p, dtype))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need the halo conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);

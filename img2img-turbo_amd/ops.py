@@ -24,7 +24,7 @@ def _keep(p, *tensors):
 
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
-         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None):
+         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None, act_out=0):
     """Implicit-GEMM conv / linear over NHWC sources.  ``w`` is packed [N][ks*ks*(c0+c1)]."""
     p = K.IgemmParams()
     c0 = x0.shape[-1] if c0 is None else c0
@@ -51,6 +51,7 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.geglu, p.out_f32, p.tile = geglu, out_f32, tile
     p.splitk, p.ws, p.subpix = splitk, ptr(ws), subpix
     p.up_h, p.up_w = up_size if up_size else (0, 0)
+    p.act_out = act_out
     return K.OP_IGEMM, _keep(p, x0, x1, w, out, gn_ss, bias, res, ws)
 
 
@@ -110,13 +111,21 @@ def softmax(s, pout, *, rows, cols, lds, ldp, scale):
     return K.OP_SOFTMAX, p
 
 
-def attention(q, k, vt, o, *, batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale):
+def attention(q, k, vt, o, *, batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, causal=0):
     p = K.AttentionParams()
     p.q, p.k, p.vt, p.o = ptr(q), ptr(k), ptr(vt), ptr(o)
     p.batch, p.heads, p.d, p.tq, p.tk = batch, heads, d, tq, tk
     p.ldq, p.ldk, p.ldvt, p.ldo = ldq, ldk, ldvt, ldo
     p.q_bs, p.k_bs, p.vt_bs, p.o_bs, p.scale = q_bs, k_bs, vt_bs, o_bs, scale
-    return K.OP_ATTENTION, p
+    p.causal = causal
+    return K.OP_ATTENTION, _keep(p, q, k, vt, o)
+
+
+def embed(ids, tok, pos, y, *, rows, T, c):
+    """y[row] = tok[ids[row]] + pos[row % T]  (CLIP text embeddings; ids int64 on the device)."""
+    p = K.EmbedParams()
+    p.ids, p.tok, p.pos, p.y, p.rows, p.T, p.c, p.vocab = ptr(ids), ptr(tok), ptr(pos), ptr(y), rows, T, c, tok.shape[0]
+    return K.OP_EMBED, _keep(p, ids, tok, pos, y)
 
 
 def nchw_to_nhwc(x, y, *, n, c, h, w, cpad, mul=1.0, add=0.0):

@@ -48,7 +48,8 @@ typedef enum {
     I2I_OP_POSTERIOR = 7,
     I2I_OP_DDPM_POSTQUANT = 8,
     I2I_OP_ATTENTION = 9,
-    I2I_OP_GN_APPLY = 10
+    I2I_OP_GN_APPLY = 10,
+    I2I_OP_EMBED = 11
 } i2i_opcode;
 
 /* ---------------------------------------------------------------------------------------------
@@ -95,6 +96,8 @@ typedef struct {
     int32_t subpix;            /* 1 (with ups = 1, ks = 3, stride 1, pad 1): `b` holds the SUB-PIXEL form of the
                                   upsample+conv, [4 parities (a,b)][N][2*2*cin] with ldb = 4*cin, tap weights
                                   pre-summed per output parity (packer.subpixel_weights); K stays 9*cin */
+    int32_t act_out;           /* epilogue activation after alpha/bias, before the residual: 0 none, 1 GELU (erf form,
+                                  CLIP ViT-H MLP), 2 quick_gelu x*sigmoid(1.702x) (CLIP ViT-L).  LDS-DMA igemm only */
     int32_t up_h, up_w;        /* ups = 1 only: explicit size of the nearest-upsampled plane (F.interpolate(size=...), the
                                   UNet's forward_upsample_size path for latent sizes that are not multiples of 8);
                                   0,0 = (2*hin, 2*win).  Source index = min(floor(i * in/up), in-1) as ATen computes it */
@@ -137,7 +140,14 @@ typedef struct {
     const void* q; const void* k; const void* vt; void* o;
     int32_t batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo;
     int64_t q_bs, k_bs, vt_bs, o_bs; float scale;
+    int32_t causal;            /* 1: query i attends to keys <= i (CLIP text tower); needs tq == tk */
 } i2i_attention_params;
+
+/* Token + position embedding of the CLIP text tower (transformers CLIPTextEmbeddings; the tokenizer side stays on the
+ * host): y[row][:] = tok[ids[row]][:] + pos[row % T][:], rows = B*T, tables and output in `dtype`. */
+typedef struct {
+    const int64_t* ids; const void* tok; const void* pos; void* y; int32_t rows, T, c, vocab;
+} i2i_embed_params;
 
 /* Boundary layout ops.  NCHW fp32/`dtype` <-> NHWC `dtype` with channel padding (zeros).
  * With src_dtype / dst_dtype = I2I_U8 the outer tensor is a uint8 image batch [n][h][w][c] (HWC, as PIL / numpy hand
@@ -186,6 +196,7 @@ typedef struct {
         i2i_nhwc_to_nchw_params to_nchw;
         i2i_posterior_params posterior;
         i2i_ddpm_params ddpm;
+        i2i_embed_params embed;
     } u;
 } i2i_op;
 
@@ -209,6 +220,7 @@ int i2i_nchw_to_nhwc(const i2i_nchw_to_nhwc_params* p, int dtype, void* stream);
 int i2i_nhwc_to_nchw(const i2i_nhwc_to_nchw_params* p, int dtype, void* stream);
 int i2i_posterior(const i2i_posterior_params* p, int dtype, void* stream);
 int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream);
+int i2i_embed(const i2i_embed_params* p, int dtype, void* stream);
 
 /* ---- programs: a forward pass is a flat array of ops executed in order on one stream ---- */
 int i2i_run(const i2i_op* ops, int n_ops, void* stream);

@@ -127,3 +127,37 @@ def test_golden_fixture_matches(tiny):
     out = pix2pix_forward(mw, x, cap, eps)
     assert (out[0, :, ::4, ::4] - g["out_sub"]).abs().max() < 1e-4
     assert abs(out.double().sum().item() - g["sum"]) < 1e-2
+
+
+def test_clip_oracle_matches_transformers():
+    """The CLIP text tower restatement (oracle/clip.py) against the installed ``transformers`` CLIPTextModel on the
+    same seeded weights: the one sub-path of the oracle that is pinned by the real implementation."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle.clip import ClipTextArch, clip_text_forward, make_clip_weights
+    for arch in (ClipTextArch(vocab_size=1000, hidden_size=128, intermediate_size=512, num_layers=3, num_heads=2),
+                 ClipTextArch(vocab_size=2000, hidden_size=1024, intermediate_size=4096, num_layers=1, num_heads=16)):
+        cfg = CLIPTextConfig(vocab_size=arch.vocab_size, hidden_size=arch.hidden_size, intermediate_size=arch.intermediate_size,
+                             num_hidden_layers=arch.num_layers, num_attention_heads=arch.num_heads,
+                             max_position_embeddings=arch.max_positions, hidden_act=arch.hidden_act, layer_norm_eps=arch.layer_norm_eps,
+                             pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        model = CLIPTextModel(cfg).eval()
+        sd = make_clip_weights(arch, seed=3)
+        own = model.state_dict()
+        mapped = {}
+        for k, v in sd.items():       # transformers 4.x keys carry "text_model."; 5.x may not
+            kk = k if k in own else k[len("text_model."):]
+            assert kk in own, k
+            mapped[kk] = v
+        missing = [k for k in own if k not in mapped and "position_ids" not in k]
+        assert not missing, missing
+        model.load_state_dict(mapped, strict=False)
+        g = torch.Generator().manual_seed(1)
+        ids = torch.randint(3, arch.vocab_size, (2, 77), generator=g)
+        ids[:, 0] = 0
+        ids[:, 40:] = 2        # eos padding as the SD tokenizer produces
+        with torch.no_grad():
+            ref = model(ids)[0]
+        got = clip_text_forward(sd, arch, ids)
+        assert (got - ref).abs().max().item() < 2e-4, (got - ref).abs().max().item()
