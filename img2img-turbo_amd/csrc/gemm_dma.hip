@@ -17,6 +17,7 @@
 //     a reduce kernel that applies the epilogue; deterministic (fixed summation order).
 // GroupNorm prologues are NOT handled here (the planner materialises act(GN(x)) for the small planes that
 // take this path); igemm.hip remains the register-staged fallback for everything this kernel declines.
+#include <cstdlib>
 #include "i2i_dev.h"
 #include "launch.h"
 
@@ -32,7 +33,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MINW>
+template <typename T, int BM, int BN, int WM, int WN, int MINW, bool PERSIST>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_igemm_params p) {
     constexpr int NW = WM * WN;
     constexpr int EPC = Elem<T>::EPC;
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ntn = (p.N + BN - 1) / BN;
-    const int tm = bid / ntn, tn = bid % ntn;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles = ((p.M + BM - 1) / BM) * ntn;
+    // PERSIST: gridDim.x < ntiles workgroups, workgroup `bid` takes tiles bid, bid + G, bid + 2G, ... and runs them
+    // as ONE continuous K-step stream (the DMA cursor runs up to three steps ahead of the MFMAs, across tile borders,
+    // so a tile's loads fly under the previous tile's MFMAs and epilogue).  Otherwise one tile per workgroup.
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     const int z = blockIdx.y, split = blockIdx.z;
     const int zb = z / p.zh_count, zh = z % p.zh_count;
 
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     unsigned pc_off[PPW];          // A: pixel index (GEMM row / image origin), B: byte offset of (row, source chunk)
     int pc_y[PPW], pc_x[PPW];      // gather only: input coordinates of tap (0,0) for an A row; y = INT_MIN/2: row >= M
     unsigned pc_chunk[PPW];        // source chunk index (for the K tail test)
+    auto setup_pieces = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int pc = wave + q * NW;
@@ -117,6 +122,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             pc_y[q] = 0; pc_x[q] = 0;
         }
     }
+    };
+    setup_pieces(m0, n0);
 
     auto dma_stage = [&](int s, int stage) __attribute__((always_inline)) {     // K step s -> ring slot `stage`
         const int k0 = s * BK;
@@ -175,65 +182,27 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     // stage s+1.  Every read is issued a whole phase before its first use, and nothing touches stage s after
     // P_s, so the DMA of step s+3 can reuse its slot immediately.
     chunk_t xa[FM], xb[FM], w0[FN], w1[FN];
-    auto xf_read = [&](int stage, int kg, int i) __attribute__((always_inline)) -> chunk_t {
-        return *(const chunk_t*)(i2i_smem + ((x_off ^ (kg * 64)) + stage * STAGE + i * 2048));
-    };
-    auto wf_read = [&](int stage, int kg, int j) __attribute__((always_inline)) -> chunk_t {
-        return *(const chunk_t*)(i2i_smem + ((w_off ^ (kg * 64)) + stage * STAGE + j * 2048));
-    };
     constexpr int NL = FM + FN, LPG = (NL + FM - 1) / FM;     // fragment loads per phase / per row group
 
-    // Row group i of a phase: LPG fragment loads for the NEXT phase, then FN MFMAs of this one (order pinned).
-    auto row_group = [&](auto stc, auto kgc, auto ic_) __attribute__((always_inline)) {
-        constexpr int st = decltype(stc)::value, kg = decltype(kgc)::value, i = decltype(ic_)::value;
-        constexpr int lst = (kg == 0) ? st : (st + 1) % 3;    // stage the loads read: own k-group 1, or next stage's k-group 0
+    // Row group i of a phase: LPG fragment loads for the NEXT phase (bases xl / wl: register + immediate), then FN
+    // MFMAs of this one (order pinned).
+    auto row_group = [&](auto kgc, auto ic_, int xl, int wl) __attribute__((always_inline)) {
+        constexpr int kg = decltype(kgc)::value, i = decltype(ic_)::value;
         constexpr int l0 = i * LPG, l1 = (l0 + LPG < NL) ? l0 + LPG : NL;
 #pragma unroll
         for (int l = l0; l < l1; ++l) {
-            if (l < FN) { if constexpr (kg == 0) w1[l] = wf_read(lst, 1, l); else w0[l] = wf_read(lst, 0, l); }
-            else        { if constexpr (kg == 0) xb[l - FN] = xf_read(lst, 1, l - FN); else xa[l - FN] = xf_read(lst, 0, l - FN); }
+            if (l < FN) { const chunk_t v = *(const chunk_t*)(i2i_smem + (wl + l * 2048)); if constexpr (kg == 0) w1[l] = v; else w0[l] = v; }
+            else        { const chunk_t v = *(const chunk_t*)(i2i_smem + (xl + (l - FN) * 2048)); if constexpr (kg == 0) xb[l - FN] = v; else xa[l - FN] = v; }
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], kg == 0 ? xa[i] : xb[i], acc[i][j]);
         if constexpr (l1 > l0) __builtin_amdgcn_sched_group_barrier(0x100, l1 - l0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, FN * MPC, 0);
     };
-    // Step s in ring slot st.  The DMA of step s+3 goes out right after P_s and is waited for at P_{s+2} with
-    // vmcnt(PPW), which leaves exactly the batch issued after P_{s+1} in flight: two steps of latency cover.
-    // (Past the last step phase B prefetches a stale stage; those fragments are never used.)
-    auto step = [&](int s, auto stc) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(stc, ic<0>{}, gc); });
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < s_end) wait_vmcnt<PPW>();
-        else wait_vmcnt<0>();
-        lds_barrier();
-        if (s + 3 < s_end) dma_stage(s + 3, decltype(stc)::value);
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(stc, ic<1>{}, gc); });
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    if (s_begin < s_end) {
-        // ---- prologue: up to three stages in flight, drain, publish ----
-        dma_stage(s_begin, 0);
-        if (s_begin + 1 < s_end) dma_stage(s_begin + 1, 1);
-        if (s_begin + 2 < s_end) dma_stage(s_begin + 2, 2);
-        wait_vmcnt<0>();
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) xa[i] = xf_read(0, 0, i);
-        for (int s = s_begin; s < s_end; s += 3) {
-            step(s, ic<0>{});
-            if (s + 1 < s_end) step(s + 1, ic<1>{});
-            if (s + 2 < s_end) step(s + 2, ic<2>{});
-        }
-    }
 
     // ---- epilogue: lane owns row m = mb + lr and, per fragment, channel quad lqc (n = nb + 4*lqc + 0..3); 16-bit
     // outputs with an even fragment count are widened to 8 consecutive n per lane (widen_pair, 16-byte stores)
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
     const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
     const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
     const int64_t r_off = (int64_t)zb * p.r_bs_b + (int64_t)zh * p.r_bs_h;
@@ -328,7 +297,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                     if (m >= p.M || n >= p.N) continue;
                     const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = act_out_f(p.alpha * v[r] + bv[r] + bm, p.act_out);
+                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r] + bm;
+                    if (p.act_out) {                       // one uniform branch per 8 values, not per value
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = act_out_f(v[r], p.act_out);
+                    }
                     if (res) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][jp][r]);
@@ -358,7 +331,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             const float bm = (p.bias_mode == 2) ? p.bias[m] : 0.f;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_out_f(p.alpha * acc[i][j][r] + bv[r] + bm, p.act_out);
+            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + bv[r] + bm;
+            if (p.act_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_out_f(v[r], p.act_out);
+            }
             if (n + 3 < p.N) {
                 if (res) {
                     const tx4 rv = *(const tx4*)(res + (int64_t)m * p.ldr + n);
@@ -384,6 +361,76 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                     }
                 }
             }
+        }
+    }
+    };
+
+    // One K step.  `cur` = ring slot of the step (runtime: ONE copy of the step in the instruction stream).  The DMA of
+    // step s+3 goes out right after P_s and is waited for at P_{s+2} with vmcnt(PPW), which leaves exactly the batch
+    // issued after P_{s+1} in flight: two steps of latency cover.  (Past the last step phase B prefetches a stale
+    // stage; those fragments are never used.)
+    // PERSIST: a tile epilogue's loads / stores sit between two DMA batches; vmcnt retires in issue order on gfx9, so
+    // vmcnt(PPW) then only waits for MORE than it needs (never less): still correct, a little conservative.
+    int cur = 0;
+    auto step = [&](bool has2, auto&& dma) __attribute__((always_inline)) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const int xA = (x_off ^ 64) + cur * STAGE, wA = (w_off ^ 64) + cur * STAGE;     // k-group 1 of this stage
+        const int xB = x_off + nxt * STAGE, wB = w_off + nxt * STAGE;                   // k-group 0 of the next one
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(ic<0>{}, gc, xA, wA); });
+        __builtin_amdgcn_sched_barrier(0);
+        if (has2) wait_vmcnt<PPW>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        dma(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(ic<1>{}, gc, xB, wB); });
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    };
+    auto first_frags = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) w0[j] = *(const chunk_t*)(i2i_smem + (w_off + j * 2048));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xa[i] = *(const chunk_t*)(i2i_smem + (x_off + i * 2048));
+    };
+
+    if constexpr (!PERSIST) {
+        if (s_begin < s_end) {
+            // ---- prologue: up to three stages in flight, drain, publish ----
+            for (int i = 0; i < 3 && s_begin + i < s_end; ++i) dma_stage(s_begin + i, i);
+            wait_vmcnt<0>();
+            lds_barrier();
+            first_frags();
+            for (int s = s_begin; s < s_end; ++s)
+                step(s + 2 < s_end, [&](int st) __attribute__((always_inline)) { if (s + 3 < s_end) dma_stage(s + 3, st); });
+        }
+        epilogue(m0, n0);
+    } else {
+        // ---- persistent stream over this workgroup's tiles (whole K per tile: no split-K, one z) ----
+        const int G = gridDim.x;
+        const int total = ((ntiles - bid + G - 1) / G) * nk;      // K steps of all my tiles
+        int d_tile = bid, d_k = 0;                                // DMA cursor: (tile, K step) of the next stage to fetch
+        auto dma_next = [&](int st) __attribute__((always_inline)) {
+            dma_stage(d_k, st);
+            if (++d_k == nk) {
+                d_k = 0; d_tile += G;
+                if (d_tile < ntiles) setup_pieces((d_tile / ntn) * BM, (d_tile % ntn) * BN);
+            }
+        };
+        for (int i = 0; i < 3 && i < total; ++i) dma_next(i);
+        wait_vmcnt<0>();
+        lds_barrier();
+        first_frags();
+        int gs = 0;
+        for (int c_tile = bid; c_tile < ntiles; c_tile += G) {
+            for (int k = 0; k < nk; ++k, ++gs)
+                step(gs + 2 < total, [&](int st) __attribute__((always_inline)) { if (gs + 3 < total) dma_next(st); });
+            epilogue((c_tile / ntn) * BM, (c_tile % ntn) * BN);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
@@ -422,6 +469,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const i2i_igemm_para
     }
 }
 
+// Workgroups of a persistent launch: all that are resident at once.  I2I_PERSIST_WGS overrides (0 = one tile per
+// workgroup always): a test / A-B hook, read per launch (launches are captured into a hipGraph anyway).
+unsigned persist_wgs(unsigned resident) {
+    const char* e = getenv("I2I_PERSIST_WGS");
+    return e ? (unsigned)atoi(e) : resident;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int MINW>
 int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
     const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
@@ -430,8 +484,16 @@ int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
     // bound: less LDS = more workgroups per CU to overlap DMA latency, MFMAs and epilogue stores)
     const int nk = (p.K + 8 * Elem<T>::EPC - 1) / (8 * Elem<T>::EPC);
     const int per = (nk + (int)nsp - 1) / (int)nsp;
-    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * (BM + BN) * 128;
-    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW>), dim3(tiles, (unsigned)p.zcount, nsp), dim3(WM * WN * 64), smem, s, p);
+    constexpr size_t STAGE = (size_t)(BM + BN) * 128;
+    // persistent stream when the tiles outnumber the resident workgroups (one z, whole K per tile)
+    constexpr unsigned OCC = (unsigned)((160 * 1024) / (3 * STAGE)), RES = 256u * (OCC < 1 ? 1u : OCC);
+    const unsigned wgs = persist_wgs(RES);
+    if (nsp == 1 && p.zcount == 1 && wgs > 0 && tiles >= 2 * wgs) {     // measured: 1.5 rounds gain nothing (tail imbalance)
+        hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, true>), dim3(wgs), dim3(WM * WN * 64), 3 * STAGE, s, p);
+        return i2i::check_launch("igemm_dma(persistent)");
+    }
+    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * STAGE;
+    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, false>), dim3(tiles, (unsigned)p.zcount, nsp), dim3(WM * WN * 64), smem, s, p);
     int rc = i2i::check_launch("igemm_dma");
     if (rc != I2I_OK || nsp == 1) return rc;
     const int64_t total = (int64_t)p.M * p.N;

@@ -159,6 +159,20 @@ def test_dma_igemm_geglu_bgemm(emu_lib, dtype):
     oc.check_bgemm(emu_lib, "cpu", dtype, out_f32=0, tile=22)
 
 
+@pytest.mark.parametrize("wgs", [1, 2, 3, 5])
+def test_dma_igemm_persistent_stream(emu_lib, wgs, monkeypatch):
+    """Persistent launch (fewer workgroups than tiles; I2I_PERSIST_WGS is the test hook): the K-step stream crosses
+    tile borders with every ring phase (nk = 1, 2, 3, 5 steps per tile), ragged M / N, gathers, GEGLU, residuals."""
+    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=200, h=9, w=23, ks=1, pad=0, res=True, alpha=0.7, tile=24)   # nk = 1
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=88, cout=72, h=19, w=23, ks=1, pad=0, res=True, tile=22)              # nk = 2, K tail
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=2, cin=96, cout=136, h=12, w=10, ks=1, pad=0, tile=23)                        # nk = 3
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=320, cout=72, h=16, w=20, ks=1, pad=0, tile=25)                        # nk = 5
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=2, cin=32, cout=40, h=12, w=10, stride=2, pad=1, tile=24)                     # 3x3 gather
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=3, cout=40, h=9, w=12, tile=24)                                       # narrow input
+    oc.check_geglu(emu_lib, "cpu", torch.bfloat16, tile=24, cff=128, rows=200)
+
+
 @pytest.mark.parametrize("splitk", [2, 3, 5])
 def test_dma_igemm_splitk(emu_lib, splitk):
     """Weight-streaming shape in miniature: few rows, long K (3x3 over 4 slabs = 36 steps), split over grid z."""
