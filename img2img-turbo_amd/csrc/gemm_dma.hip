@@ -84,6 +84,26 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     const int s_begin = split * per;
     const int s_end = (s_begin + per < nk) ? s_begin + per : nk;
 
+    // ---- per-n bias through LDS: one extra DMA op fetches the tile's BN floats into a 1 KiB slot behind the stage ring
+    // (PERSIST: ring of 4 slots, one op in EVERY batch so the per-batch op count stays uniform), so the epilogue has
+    // no global load that would have to wait (vmcnt is in-order) for the DMA batches in flight.
+    const bool lb = p.bias && (p.geglu || p.bias_mode == 1) && (p.N & 3) == 0 && (((uintptr_t)p.bias & 15) == 0);
+    const int bias_base = (PERSIST ? 3 : (per < 3 ? (per < 1 ? 1 : per) : 3)) * STAGE;
+    auto bias_dma = [&](int n0, int slot) __attribute__((always_inline)) {
+        const int c = lane * 4;
+        const bool ok = lb && c < BN && n0 + c < p.N;
+        glds16(ok ? (const char*)(p.bias + n0 + c) : zero, i2i_smem + bias_base + slot * 1024);
+    };
+    auto bias4 = [&](int n, int n0, int slot) __attribute__((always_inline)) -> f32x4 {    // bias[n .. n+3] of the tile at n0
+        if (lb) return *(const f32x4*)(i2i_smem + bias_base + slot * 1024 + (n - n0) * 4);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && (p.geglu || p.bias_mode == 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
+        }
+        return b;
+    };
+
     // ---- this wave's DMA pieces: pc = wave + q*NW; pc < PA -> A rows pc*8.., else B rows (pc-PA)*8.. ----
     // per lane: row = 8*piece + (lane>>3), physical chunk lane&7 holds source chunk (lane&7) ^ swz(row)
     unsigned pc_off[PPW];          // A: pixel index (GEMM row / image origin), B: byte offset of (row, source chunk)
@@ -202,7 +222,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 
     // ---- epilogue: lane owns row m = mb + lr and, per fragment, channel quad lqc (n = nb + 4*lqc + 0..3); 16-bit
     // outputs with an even fragment count are widened to 8 consecutive n per lane (widen_pair, 16-byte stores)
-    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    // Returns the number of store instructions this wave is GUARANTEED to have issued (0 = unknown): the persistent
+    // stream adds it to its counted vmcnt so the next barrier does not wait for the stores to be acknowledged.
+    auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
+    const bool exact = m0 + BM <= p.M && n0 + BN <= p.N;
     const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
     const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
     const int64_t r_off = (int64_t)zb * p.r_bs_b + (int64_t)zh * p.r_bs_h;
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 }
             }
         }
-        return;
+        return 0;
     }
     const T* __restrict__ res = p.res ? (const T*)p.res + r_off : nullptr;
     if (p.geglu) {
@@ -235,11 +258,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 const int nG = nA + 16;
                 const int no = (n0 + wn * WTN + j * 16) / 2 + lqc * 4;    // output column of the 4 results
                 if (nG >= p.N) continue;
-                float bA[4] = {0.f, 0.f, 0.f, 0.f}, bG[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { bA[r] = p.bias[nA + r]; bG[r] = p.bias[nG + r]; }
-                }
+                const f32x4 bA = bias4(nA, n0, slot), bG = bias4(nG, n0, slot);
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * WTM + i * 16 + lr;
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 }
             }
         }
-        return;
+        return (exact && FN >= 2) ? FM * (FN / 2) : 0;
     }
     const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0) &&
                       (((c_off | r_off) & 7) == 0) && (((uintptr_t)p.res & 15) == 0);
@@ -287,8 +306,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             for (int jp = 0; jp < FN / 2; ++jp) {
                 const int n = n0 + wn * WTN + (2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8;
                 float bv[8];
+                {
+                    const f32x4 b0 = bias4(n < p.N ? n : n0, n0, slot), b1 = bias4(n < p.N ? n + 4 : n0, n0, slot);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N) ? p.bias[n + r] : 0.f;
+                    for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     float v[8];
@@ -313,17 +335,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 }
             }
         }
-        return;
+        return exact ? FM * (FN / 2) : 0;
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * WTN + j * 16 + lqc * 4;
         if (n >= p.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
-        }
+        const f32x4 bv = bias4(n, n0, slot);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * WTM + i * 16 + lr;
@@ -363,24 +381,30 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             }
         }
     }
+    return 0;
     };
 
-    // One K step.  `cur` = ring slot of the step (runtime: ONE copy of the step in the instruction stream).  The DMA of
-    // step s+3 goes out right after P_s and is waited for at P_{s+2} with vmcnt(PPW), which leaves exactly the batch
-    // issued after P_{s+1} in flight: two steps of latency cover.  (Past the last step phase B prefetches a stale
-    // stage; those fragments are never used.)
-    // PERSIST: a tile epilogue's loads / stores sit between two DMA batches; vmcnt retires in issue order on gfx9, so
-    // vmcnt(PPW) then only waits for MORE than it needs (never less): still correct, a little conservative.
+    // One K step.  `cur` = ring slot of the step (runtime: ONE copy of the step in the instruction stream).  The DMA
+    // batch of step s+3 (B_s) goes out right after P_s and is waited for at P_{s+2} with a counted vmcnt that leaves
+    // everything issued after it in flight: two steps of latency cover.  vmcnt retires in issue order on gfx9, so
+    // "B_{s-2} has landed" == "at most (ops issued after B_{s-2}) outstanding" = OPB (batch B_{s-1}) plus, in the
+    // persistent stream, the stores of the tile epilogues that ran after steps s-2 and s-1 (`est` groups of NST
+    // guaranteed stores; epilogues that cannot guarantee a count contribute 0, which only waits longer).
+    // (Past the last step phase B prefetches a stale stage; those fragments are never used.)
+    constexpr int OPB = PPW + (PERSIST ? 1 : 0);       // DMA ops per in-loop batch (persistent: + the bias slot)
+    constexpr int NST = FM * (FN / 2);
     int cur = 0;
-    auto step = [&](bool has2, auto&& dma) __attribute__((always_inline)) {
+    auto step = [&](bool has2, int est, auto&& dma) __attribute__((always_inline)) {
         const int nxt = cur == 2 ? 0 : cur + 1;
         const int xA = (x_off ^ 64) + cur * STAGE, wA = (w_off ^ 64) + cur * STAGE;     // k-group 1 of this stage
         const int xB = x_off + nxt * STAGE, wB = w_off + nxt * STAGE;                   // k-group 0 of the next one
         __builtin_amdgcn_sched_barrier(0);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(ic<0>{}, gc, xA, wA); });
         __builtin_amdgcn_sched_barrier(0);
-        if (has2) wait_vmcnt<PPW>();
-        else wait_vmcnt<0>();
+        if (!has2) wait_vmcnt<0>();
+        else if (!PERSIST || est == 0) wait_vmcnt<OPB>();
+        else if (est == 1) wait_vmcnt<OPB + NST>();
+        else wait_vmcnt<OPB + 2 * NST>();
         lds_barrier();
         dma(cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -397,24 +421,26 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 
     if constexpr (!PERSIST) {
         if (s_begin < s_end) {
-            // ---- prologue: up to three stages in flight, drain, publish ----
+            // ---- prologue: up to three stages (+ the bias slot) in flight, drain, publish ----
             for (int i = 0; i < 3 && s_begin + i < s_end; ++i) dma_stage(s_begin + i, i);
+            if (nsp == 1) bias_dma(n0, 0);
             wait_vmcnt<0>();
             lds_barrier();
             first_frags();
             for (int s = s_begin; s < s_end; ++s)
-                step(s + 2 < s_end, [&](int st) __attribute__((always_inline)) { if (s + 3 < s_end) dma_stage(s + 3, st); });
+                step(s + 2 < s_end, 0, [&](int st) __attribute__((always_inline)) { if (s + 3 < s_end) dma_stage(s + 3, st); });
         }
-        epilogue(m0, n0);
+        epilogue(m0, n0, 0);
     } else {
         // ---- persistent stream over this workgroup's tiles (whole K per tile: no split-K, one z) ----
         const int G = gridDim.x;
         const int total = ((ntiles - bid + G - 1) / G) * nk;      // K steps of all my tiles
-        int d_tile = bid, d_k = 0;                                // DMA cursor: (tile, K step) of the next stage to fetch
+        int d_tile = bid, d_k = 0, d_ord = 0;                     // DMA cursor: (tile, K step) of the next stage to fetch
         auto dma_next = [&](int st) __attribute__((always_inline)) {
             dma_stage(d_k, st);
+            bias_dma((d_tile % ntn) * BN, d_ord & 3);
             if (++d_k == nk) {
-                d_k = 0; d_tile += G;
+                d_k = 0; d_tile += G; ++d_ord;
                 if (d_tile < ntiles) setup_pieces((d_tile / ntn) * BM, (d_tile % ntn) * BN);
             }
         };
@@ -422,11 +448,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
         wait_vmcnt<0>();
         lds_barrier();
         first_frags();
-        int gs = 0;
-        for (int c_tile = bid; c_tile < ntiles; c_tile += G) {
-            for (int k = 0; k < nk; ++k, ++gs)
-                step(gs + 2 < total, [&](int st) __attribute__((always_inline)) { if (gs + 3 < total) dma_next(st); });
-            epilogue((c_tile / ntn) * BM, (c_tile % ntn) * BN);
+        int gs = 0, c_ord = 0;
+        int e1 = 0, e2 = 0;             // 1 if the epilogue after the previous / second-previous step left NST counted stores
+        for (int c_tile = bid; c_tile < ntiles; c_tile += G, ++c_ord) {
+            for (int k = 0; k < nk; ++k, ++gs) {
+                step(gs + 2 < total, e1 + e2, [&](int st) __attribute__((always_inline)) { if (gs + 3 < total) dma_next(st); });
+                e2 = e1; e1 = 0;
+            }
+            e1 = epilogue((c_tile / ntn) * BM, (c_tile % ntn) * BN, c_ord & 3) == NST ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -486,13 +515,13 @@ int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
     const int per = (nk + (int)nsp - 1) / (int)nsp;
     constexpr size_t STAGE = (size_t)(BM + BN) * 128;
     // persistent stream when the tiles outnumber the resident workgroups (one z, whole K per tile)
-    constexpr unsigned OCC = (unsigned)((160 * 1024) / (3 * STAGE)), RES = 256u * (OCC < 1 ? 1u : OCC);
+    constexpr unsigned OCC = (unsigned)((160 * 1024) / (3 * STAGE + 4096)), RES = 256u * (OCC < 1 ? 1u : OCC);
     const unsigned wgs = persist_wgs(RES);
     if (nsp == 1 && p.zcount == 1 && wgs > 0 && tiles >= 2 * wgs) {     // measured: 1.5 rounds gain nothing (tail imbalance)
-        hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, true>), dim3(wgs), dim3(WM * WN * 64), 3 * STAGE, s, p);
+        hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, true>), dim3(wgs), dim3(WM * WN * 64), 3 * STAGE + 4096, s, p);
         return i2i::check_launch("igemm_dma(persistent)");
     }
-    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * STAGE;
+    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * STAGE + 1024;      // + the bias slot
     hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, false>), dim3(tiles, (unsigned)p.zcount, nsp), dim3(WM * WN * 64), smem, s, p);
     int rc = i2i::check_launch("igemm_dma");
     if (rc != I2I_OK || nsp == 1) return rc;

@@ -98,6 +98,21 @@ def test_dma_igemm_every_tile_config(gpu_lib, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [20, 22, 24, 25])
+def test_dma_igemm_persistent_stream(gpu_lib, cfg):
+    """Many more tiles than resident workgroups: the persistent K-step stream (counted vmcnt across tile borders, bias
+    ring in LDS, in-loop epilogues) on the real hardware, short K (1, 2, 5 steps), exact and ragged tiles, repeated
+    so a missing wait shows up as a mismatch."""
+    for rep in range(3):
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=4, cin=64, cout=256, h=128, w=128, ks=1, pad=0, res=True, tile=cfg, seed=rep)     # nk=1, exact
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=264, h=131, w=127, ks=1, pad=0, tile=cfg, seed=rep)              # nk=2, ragged
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=4, cin=320, cout=640, h=64, w=64, ks=1, pad=0, res=True, alpha=0.5, tile=cfg, seed=rep)   # nk=5
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=3, cout=128, h=192, w=192, tile=cfg, seed=rep)                             # narrow gather
+    oc.check_conv(gpu_lib, "cuda", torch.float32, n=2, cin=96, cout=256, h=128, w=128, ks=1, pad=0, res=True, tile=cfg)
+    oc.check_geglu(gpu_lib, "cuda", torch.bfloat16, tile=cfg, rows=16384, cin=320, cff=1280)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
     oc.check_geglu(gpu_lib, "cuda", dtype, tile=20, rows=300, cin=320, cff=1280)
