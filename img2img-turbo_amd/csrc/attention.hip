@@ -12,6 +12,7 @@
 // Running max / sum / rescale all belong to query l&15 = this lane: no cross-lane traffic except two
 // xor-shuffles (16, 32) per tile for the max.  V arrives transposed (V^T [heads*d][Tk]) straight from the
 // projection GEMM (weights as the A operand), so no transpose pass exists anywhere.
+#include <type_traits>
 #include "i2i_dev.h"
 #include "launch.h"
 
@@ -195,6 +196,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const i2i_attention_para
 //   * scores are scaled by scale*log2(e) once and exponentiated with v_exp_f32 (2^x) directly;
 //   * rows / chunks past tk read a 16-byte zero block; the partially valid last V^T chunk (tk % 8 != 0) is cleaned
 //     in LDS before use (its padding may hold anything, and 0 * NaN would poison the output).
+// XCD-aware workgroup order for the DMA attention kernels (1-D grid; workgroup id -> XCD id % 8): every (batch, head)
+// group keeps all its query tiles on ONE XCD, so its K / V^T tiles are fetched into that XCD's L2 once and hit by the
+// other query tiles, instead of every XCD streaming every group from the fabric.  Groups g, g + 8, ... share an XCD
+// one after the other.  Grid = ceil(groups / 8) * 8 * nqt; returns false for the padding workgroups.
+__device__ __forceinline__ bool att_group_of_block(int nqt, int heads, int batch, int& qt, int& h, int& b) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = (slot / nqt) * 8 + xcd;
+    qt = slot % nqt;
+    h = g % heads;
+    b = g / heads;
+    return g < heads * batch;
+}
+inline unsigned att_grid(int nqt, int heads, int batch) { return (unsigned)(((heads * batch + 7) / 8) * 8 * nqt); }
+
 __device__ __attribute__((aligned(16))) uint32_t g_att_zero16[4] = {0u, 0u, 0u, 0u};
 
 template <typename T>
@@ -204,8 +219,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     constexpr int D = 64, BKV = 64, QF = 2, STAGE = 2 * BKV * 128, PPW = 4;   // 16 one-KiB pieces per stage, 4 per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int qt, h, b;
+    if (!att_group_of_block((p.tq + 127) / 128, p.heads, p.batch, qt, h, b)) return;
+    const int q0 = qt * 128 + wave * 32;
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
@@ -243,6 +259,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
         for (int kg = 0; kg < 2; ++kg)
             qfr[f][kg] = (qi < p.tq) ? *(const chunk_t*)(qp + (int64_t)qi * p.ldq + (kg * 4 + lq) * 8) : zero_chunk<T>();
     }
+    // the compiler must see the Q loads retired BEFORE the tile loop: otherwise (it cannot see the hand-written counted
+    // waits) it drains vmcnt to 0 at their first use INSIDE the loop, every tile, and the DMA ring never overlaps
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) reg_fence(qfr[f][kg]);
     f32x4 oacc[QF][4];
 #pragma unroll
     for (int f = 0; f < QF; ++f)
@@ -286,39 +308,48 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
                 sacc[f][kf] = a;
             }
         }
-        // ---- online softmax, lane-local per query apart from two xor-shuffles for the max ----
-        const bool tail = kv0 + BKV > p.tk;
+        // ---- online softmax, lane-local per query apart from two xor-shuffles for the max.  The softmax is the VALU
+        // bound of this kernel (d = 64: 32 v_exp per 32 MFMAs), so: the running max is kept in RAW score units (scale > 0:
+        // same argmax), scale*log2(e) is folded into one FMA per probability, and the key masks (key tail, causal) are
+        // only evaluated on the tiles that can be masked at all ----
+        const bool need_mask = (kv0 + BKV > p.tk) || (p.causal && kv0 + BKV - 1 > q0);
+        auto softmax = [&](auto maskc) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(maskc)::value;
 #pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            float mt = -1e30f;
+            for (int f = 0; f < QF; ++f) {
+                float mt = -1e30f;
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sv = sacc[f][kf][r] * c2;
-                    const int key = kv0 + kf * 16 + lq * 4 + r;
-                    if ((tail && key >= p.tk) || (p.causal && key > q0 + f * 16 + lr)) sv = -1e30f;
-                    sacc[f][kf][r] = sv;
-                    mt = fmaxf(mt, sv);
-                }
-            mt = fmaxf(mt, __shfl_xor(mt, 16));
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float m_new = fmaxf(m_run[f], mt);
-            const float alpha = exp2_fast(m_run[f] - m_new);
-            float psum = 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (MASK) {
+                            const int key = kv0 + kf * 16 + lq * 4 + r;
+                            if (key >= p.tk || (p.causal && key > q0 + f * 16 + lr)) sacc[f][kf][r] = -1e30f;
+                        }
+                        mt = fmaxf(mt, sacc[f][kf][r]);
+                    }
+                mt = fmaxf(mt, __shfl_xor(mt, 16));
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float m_new = fmaxf(m_run[f], mt);
+                const float alpha = exp2_fast((m_run[f] - m_new) * c2);
+                const float mc = m_new * c2;
+                float psum = 0.f;
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2_fast(sacc[f][kf][r] - m_new);
-                    sacc[f][kf][r] = pv;
-                    psum += pv;
-                }
-            l_run[f] = l_run[f] * alpha + psum;             // per-lane partial; quads are summed once at the end
-            m_run[f] = m_new;
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = exp2_fast(__builtin_fmaf(sacc[f][kf][r], c2, -mc));
+                        sacc[f][kf][r] = pv;
+                        psum += pv;
+                    }
+                l_run[f] = l_run[f] * alpha + psum;             // per-lane partial; quads are summed once at the end
+                m_run[f] = m_new;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
-        }
+                for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
+            }
+        };
+        if (need_mask) softmax(std::true_type{});
+        else softmax(std::false_type{});
         // ---- O^T += V^T P^T : keys 32g + 4lq..+3 and 32g + 16 + 4lq..+3 of V^T row 16i + lr ----
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -358,9 +389,247 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide-head flash attention for the 16-bit types: ONE head of width D = 512, the AutoencoderKL mid-block attention
+// (diffusers Attention with heads = 1 over the 64x64 latent plane: T = 4096 at 512x512).  Replaces the materialised
+// scores / softmax / p.v chain (fp32 [B][T][T] scores through HBM) with the same swapped-matmul scheme as above:
+//   * a wave owns 16 queries: Q^T fragments (D/32 chunks = 64 VGPRs) and the whole O^T accumulator (D/16 fragments =
+//     128 VGPRs) live in registers; workgroup = 8 waves = 128 queries, 2 waves / SIMD;
+//   * key tiles of 32: K tile [32 keys][D] (32 KiB, rows of D/8 chunks, chunk ^= row & 15) and V^T tile [D][32 keys]
+//     (32 KiB, rows of 4 chunks, chunk ^= (row >> 2) & 3) arrive by global_load_lds_dwordx4, double buffered:
+//     tile t+1 is requested right after the barrier that opens tile t, and waited for one whole tile later;
+//   * every fragment read feeds one MFMA here (16 queries per wave), so LDS read bandwidth and the matrix pipe are
+//     balanced by construction; the O^T rescale is skipped when no running max moved in the wave (the common case
+//     after the first tiles).
+template <typename T, int D, int QF, int NW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(const i2i_attention_params p) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    static_assert(Elem<T>::EPC == 8 && D % 128 == 0, "16-bit types, D a multiple of 128");
+    constexpr int BKV = 32;
+    constexpr int CPRK = D / 8;                     // 16-byte chunks per K row
+    constexpr int KC = D / 32, DF = D / 16;         // k-chunks over d (S^T), output fragments over d (O^T)
+    constexpr int KTILE = BKV * D * 2, VTILE = D * 64, STAGE = KTILE + VTILE;
+    constexpr int OPS = (BKV + D / 16) / NW;        // one-KiB DMA ops per wave and stage
+    constexpr int LOOK = 4;                         // fragment reads in flight ahead of the MFMAs that consume them
+    constexpr int BQ = NW * QF * 16;                // queries per workgroup
+    static_assert((BKV + D / 16) % NW == 0, "");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    int qt, h, b;
+    if (!att_group_of_block((p.tq + BQ - 1) / BQ, p.heads, p.batch, qt, h, b)) return;
+    const int q0 = qt * BQ + wave * (QF * 16);
+
+    const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
+    const char* vp = (const char*)((const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)h * D * p.ldvt);
+    const int ntile = (p.tk + BKV - 1) / BKV;
+    auto voff = [](int row, int c) __attribute__((always_inline)) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); };
+
+    // op pc = q*NW + wave; pc < BKV: K row pc (one key, D/8 chunks = 64 lanes), else 16 V^T rows (4 chunks each).
+    // Sources are uniform base + 32-bit lane offset (no per-lane 64-bit pointers: the O^T accumulator needs the
+    // registers).  Keys past tk: the K row is clamped to the last key (its scores are masked), a V^T chunk entirely
+    // past tk re-reads the row's chunk 0 (finite, and its probabilities are exact zeros; the host checks tk >= 8).
+    auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
+        const int kv0 = t * BKV;
+        char* dst = i2i_smem + stage * STAGE;
+        int ln = lane;
+#ifndef I2I_EMU
+        asm volatile("" : "+v"(ln));     // opaque: the per-op lane offsets are recomputed every tile (a few VALU) instead of
+                                         // being hoisted out of the loop into registers the fragment look-ahead needs
+#endif
+#pragma unroll
+        for (int q = 0; q < OPS; ++q) {
+            const int pc = q * NW + wave;
+            if (pc < BKV) {
+                int key = kv0 + pc;
+                key = key < p.tk ? key : p.tk - 1;
+                const unsigned sc = (unsigned)(ln ^ (pc & 15));          // source chunk of physical chunk `lane` (att_off<CPRK>)
+                glds16(kp + ((unsigned)key * (unsigned)p.ldk + sc * 8u) * (unsigned)sizeof(T), dst + pc * 1024);
+            } else {
+                const int row = (pc - BKV) * 16 + (ln >> 2);
+                const int sc = (ln & 3) ^ ((row >> 2) & 3);
+                int key0 = kv0 + sc * 8;
+                key0 = key0 < p.tk ? key0 : 0;
+                glds16(vp + ((unsigned)row * (unsigned)p.ldvt + (unsigned)key0) * (unsigned)sizeof(T), dst + pc * 1024);
+            }
+        }
+    };
+    static_assert(CPRK == 64, "one K row per DMA op (64 lanes x 16 bytes)");
+
+    // K fragment (key row 16kf + lr, chunk 4kc + lq) sits at physical chunk (4kc + lq) ^ lr = 16(kc>>2) + 4((kc&3) ^ (lr>>2))
+    // + (lq ^ (lr&3)): four per-lane bases, everything else is an immediate
+    int kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kb[j] = lr * (CPRK * 16) + ((((j ^ (lr >> 2)) << 2) + (lq ^ (lr & 3))) << 4);
+    chunk_t qfr[QF][KC];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int qi = q0 + f * 16 + lr;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            qfr[f][kc] = (qi < p.tq) ? *(const chunk_t*)(qp + (int64_t)qi * p.ldq + (kc * 4 + lq) * 8) : zero_chunk<T>();
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) reg_fence(qfr[f][kc]);     // Q loads retired before the loop (see attention_dma_kernel)
+    f32x4 oacc[QF][DF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int i = 0; i < DF; ++i) oacc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
+    const float c2 = p.scale * 1.44269504088896341f;
+
+    dma_tile(0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        const int st = t & 1, kv0 = t * BKV;
+        wait_vmcnt<0>();                 // tile t has landed (requested one tile ago)
+        lds_barrier();                   // ... for everyone, and everyone is done reading tile t-1
+        if (t + 1 < ntile) dma_tile(t + 1, st ^ 1);
+        const char* Ks = i2i_smem + st * STAGE;
+        const char* Vs = Ks + KTILE;
+        if (kv0 + BKV > p.tk && (p.tk & 7)) {              // last tile, partially valid V^T chunk: clean its tail in LDS
+            const int kc = (p.tk - kv0) >> 3, first = (p.tk - kv0) & 7;
+            for (int row = tid; row < D; row += NW * 64) {
+                T* e = (T*)(i2i_smem + st * STAGE + KTILE + voff(row, kc));
+                for (int j = first; j < 8; ++j) e[j] = (T)0.0f;
+            }
+            lds_barrier();
+        }
+        // ---- S^T = K Q^T : sacc[f][kf][r] = S[query q0+16f+lr][key kv0 + 16kf + 4lq + r] ----
+        // (2*QF independent accumulation chains, interleaved; every K fragment read feeds QF MFMAs; reads run LOOK
+        // fragments ahead, pinned so the compiler neither serialises read -> wait -> MFMA nor hoists a whole tile)
+        f32x4 sacc[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) sacc[f][0] = sacc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            // explicit software pipeline: fragment n = (kc = n>>1, kf = n&1) is read LOOK fragments before its MFMAs
+            auto kread = [&](int n) __attribute__((always_inline)) -> chunk_t {
+                const int kc = n >> 1, kf = n & 1;
+                return *(const chunk_t*)(Ks + (kb[kc & 3] + kf * 16 * CPRK * 16 + (kc >> 2) * 256));
+            };
+            chunk_t fr[LOOK];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < LOOK; ++n) fr[n] = kread(n);
+            __builtin_amdgcn_sched_group_barrier(0x100, LOOK, 0);
+#pragma unroll
+            for (int n = 0; n < 2 * KC; ++n) {
+#pragma unroll
+                for (int f = 0; f < QF; ++f) sacc[f][n & 1] = mma_chunk(fr[n % LOOK], qfr[f][n >> 1], sacc[f][n & 1]);
+                __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
+                if (n + LOOK < 2 * KC) {
+                    fr[n % LOOK] = kread(n + LOOK);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- online softmax (lane-local per query, two xor-shuffles for the max) ----
+        const bool tail = kv0 + BKV > p.tk;
+        float alpha[QF];
+        bool moved = false;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mt = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = sacc[f][kf][r] * c2;
+                    if (tail && kv0 + kf * 16 + lq * 4 + r >= p.tk) sv = -1e30f;
+                    sacc[f][kf][r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run[f], mt);
+            alpha[f] = exp2_fast(m_run[f] - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2_fast(sacc[f][kf][r] - m_new);
+                    sacc[f][kf][r] = pv;
+                    psum += pv;
+                }
+            l_run[f] = l_run[f] * alpha[f] + psum;
+            moved = moved || (m_new != m_run[f]);
+            m_run[f] = m_new;
+        }
+        if (wave_any(moved)) {           // wave-uniform: rescale O^T only when some query's running max moved
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int i = 0; i < DF; ++i) oacc[f][i] *= alpha[f];
+        }
+        // ---- O^T += V^T P^T : keys 4lq..+3 and 16 + 4lq..+3 of V^T row 16i + lr ----
+        chunk_t pb[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) pb[f] = pack_p(sacc[f][0], sacc[f][1], T());
+        {
+            union vfrag { chunk_t c; uint64_t u[2]; };
+            auto vread = [&](int i) __attribute__((always_inline)) -> chunk_t {
+                const int row = i * 16 + lr;
+                vfrag a;
+                a.u[0] = *(const uint64_t*)(Vs + voff(row, lq >> 1) + (lq & 1) * 8);
+                a.u[1] = *(const uint64_t*)(Vs + voff(row, 2 + (lq >> 1)) + (lq & 1) * 8);
+                return a.c;
+            };
+            chunk_t fr[LOOK];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < LOOK; ++n) fr[n] = vread(n);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * LOOK, 0);
+#pragma unroll
+            for (int i = 0; i < DF; ++i) {
+#pragma unroll
+                for (int f = 0; f < QF; ++f) oacc[f][i] = mma_chunk(fr[i % LOOK], pb[f], oacc[f][i]);
+                __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
+                if (i + LOOK < DF) {
+                    fr[i % LOOK] = vread(i + LOOK);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l_tot = l_run[f];
+        l_tot += __shfl_xor(l_tot, 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + f * 16 + lr;
+        if (qi < p.tq) {
+            T* op = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D;
+            typedef T tx4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < DF; ++i) {
+                tx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[f][i][r] * inv);
+                *(tx4*)(op + i * 16 + lq * 4) = o;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_att_wide(const i2i_attention_params& p, hipStream_t s) {
+    constexpr int QF = 1, NW = 8;                  // 8 waves x 16 queries, two waves per SIMD (256 registers each)
+    const dim3 grid(att_grid((p.tq + NW * QF * 16 - 1) / (NW * QF * 16), p.heads, p.batch));
+    hipLaunchKernelGGL((attention_wide_kernel<T, 512, QF, NW>), grid, dim3(NW * 64), (size_t)2 * (32 * 512 * 2 + 512 * 64), s, p);
+    return i2i::check_launch("attention_wide");
+}
+
 template <typename T>
 int launch_att_dma(const i2i_attention_params& p, hipStream_t s) {
-    const dim3 grid((unsigned)((p.tq + 127) / 128), (unsigned)p.heads, (unsigned)p.batch);
+    const dim3 grid(att_grid((p.tq + 127) / 128, p.heads, p.batch));
     hipLaunchKernelGGL((attention_dma_kernel<T>), grid, dim3(256), (size_t)3 * 2 * 64 * 128, s, p);
     return i2i::check_launch("attention_dma");
 }
@@ -377,17 +646,26 @@ int launch_att(const i2i_attention_params& p, hipStream_t s) {
 
 extern "C" int i2i_attention(const i2i_attention_params* p, int dtype, void* stream) {
     if (!p || !p->q || !p->k || !p->vt || !p->o) return i2i::fail(I2I_ERR_BAD_ARG, "attention: null pointer");
-    if (p->d != 64) return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: fused kernel supports head dim 64 only (got %d)", p->d);
+    if (p->d != 64 && !(p->d == 512 && dtype != I2I_F32))
+        return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: fused kernels support head dim 64, and 512 for the 16-bit types (got %d)", p->d);
     const int epc = dtype == I2I_F32 ? 4 : 8;
     if (p->ldq % epc || p->ldk % epc || p->ldvt % epc || p->ldo % 4 || p->tk < 1 || p->tq < 1)
         return i2i::fail(I2I_ERR_BAD_ARG, "attention: bad leading dims");
     if (p->ldvt < ((p->tk + epc - 1) / epc) * epc) return i2i::fail(I2I_ERR_BAD_ARG, "attention: ldvt must cover tk rounded up to a chunk");
+    if (!(p->scale > 0.f)) return i2i::fail(I2I_ERR_BAD_ARG, "attention: scale must be positive");
     if (p->causal && p->tq != p->tk) return i2i::fail(I2I_ERR_BAD_ARG, "attention: causal needs tq == tk");
     hipStream_t s = (hipStream_t)stream;
     // 16-bit types: LDS-DMA kernel (needs 8-byte aligned output rows for its vector stores); f32 parity mode: the
     // register-staged kernel
     const bool dma_ok = (p->ldo % 4 == 0) && (p->o_bs % 4 == 0) && (((uintptr_t)p->o & 7) == 0) && (((uintptr_t)p->k | (uintptr_t)p->vt) & 15) == 0 &&
                         (p->ldk % 8 == 0) && (p->k_bs % 8 == 0) && (p->vt_bs % 8 == 0);
+    if (p->d == 512) {
+        if (!dma_ok || p->causal || p->ldq % 8 || (((uintptr_t)p->q) & 15) || p->q_bs % 8 || p->tk < 8 ||
+            (int64_t)p->tk * p->ldk * 2 >= (int64_t(1) << 32) || (int64_t)p->d * p->heads * p->ldvt * 2 >= (int64_t(1) << 32))
+            return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: the d = 512 kernel needs 16-byte aligned q / k / v^T rows, tk >= 8, "
+                                                  "per-batch K / V^T under 4 GiB and no causal mask");
+        return dtype == I2I_BF16 ? launch_att_wide<__bf16>(*p, s) : launch_att_wide<_Float16>(*p, s);
+    }
     switch (dtype) {
         case I2I_F32: return launch_att<float>(*p, s);
         case I2I_BF16: return dma_ok ? launch_att_dma<__bf16>(*p, s) : launch_att<__bf16>(*p, s);

@@ -64,8 +64,14 @@ __device__ __forceinline__ f32x4 mma_chunk(f16x8 a, f16x8 b, f32x4 acc) {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 #ifdef I2I_EMU
 __device__ __forceinline__ float exp2_fast(float x) { return exp2f(x); }
+__device__ __forceinline__ bool wave_any(bool c) {           // true in every lane iff c holds in some lane of the wave
+    int v = c ? 1 : 0;
+    for (int m = 1; m < 64; m <<= 1) v |= __shfl_xor(v, m);
+    return v != 0;
+}
 #else
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32 (2^x, ~1 ulp)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 #endif
 // Exact-form GELU (F.gelu default, erf based) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32
 // round-off class): one v_rcp_f32 + one v_exp_f32 + 8 FMAs instead of libm's erff (~40 VALU) -- the GEGLU epilogue

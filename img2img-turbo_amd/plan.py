@@ -72,7 +72,7 @@ class ForwardPlan:
     """One planned forward for fixed (B, H, W, dtype, r, direction)."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         # H, W multiples of 8 suffice (src/inference_paired.py:38-41): latent sizes that are not multiples of 8 make the
         # UNet levels odd (70 -> 35 -> 18 -> 9), handled like diffusers' forward_upsample_size path (explicit sizes).
@@ -82,6 +82,7 @@ class ForwardPlan:
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
         self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
+        self.fuse_vae_attention = fuse_vae_attention   # d = 512 flash kernel for the VAE mid-block attention (16-bit types)
         self.halo_min_tiles = halo_min_tiles   # fewer halo-conv tiles than this: LDS-DMA igemm + split-K instead
         self.subpix = subpix         # Upsample2D convs in sub-pixel form (4 parity 2x2 convs on the source plane)
         self.dma_small = dma_small   # non-halo GN convs: materialise GN and use the LDS-DMA igemm (+ split-K)
@@ -328,6 +329,18 @@ class ForwardPlan:
                           b_bs=(T * C, 0), c_bs=(C * Tp, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T")
         self.flops += 2 * B * T * C * C
         self.free(xn)
+        if C == 512 and self.dtype != torch.float32 and T >= 8 and self.fuse_vae_attention:
+            # one head of width 512: the wide-head flash kernel (attention.hip), scores never leave the CU
+            o = self.pool.get(B * T * C, self.dtype)
+            self._add(O.attention(qk, qk[C:], vt, o, batch=B, heads=1, d=C, tq=T, tk=T, ldq=2 * C, ldk=2 * C, ldvt=Tp, ldo=C,
+                                  q_bs=T * 2 * C, k_bs=T * 2 * C, vt_bs=C * Tp, o_bs=T * C, scale=1.0 / math.sqrt(C)), prefix + ".sdpa")
+            self.flops += 4 * B * T * T * C
+            self.pool.put(qk)
+            self.pool.put(vt)
+            out = self.new(x.n, x.h, x.w, C)
+            self.linear(pk.conv(prefix + ".to_out.0"), o, B * T, C, out=out.t, res=x.t, label=prefix + ".to_out")
+            self.pool.put(o)
+            return out
         s = self.pool.get(B * T * Tp, torch.float32)
         self._add(O.bgemm(qk, qk[C:], s, M=T, N=T, Kdim=C, lda=2 * C, ldb=2 * C, ldc=Tp, batch=B, heads=1,
                           a_bs=(T * 2 * C, 0), b_bs=(T * 2 * C, 0), c_bs=(T * Tp, 0), out_f32=1), prefix + ".qk^T")

@@ -241,6 +241,14 @@ def test_u8_boundary(emu_lib, dtype):
     oc.check_u8_boundary(emu_lib, "cpu", dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_wide_head(emu_lib, dtype):
+    """attention_wide_kernel (one head of 512: the VAE mid-block attention): several key tiles of 32 (double buffer
+    wrap-around), query tails, a key tail that is not a chunk multiple (poisoned V^T padding), late max jump."""
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, d=512, tq=130, tk=64)
+
+
 def test_dma_igemm_narrow_input_conv(emu_lib):
     """VAE conv_in shape class: 3 -> 8 padded input channels, several taps per K step (per-chunk tap decode)."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=3, cout=40, h=9, w=12, tile=20)

@@ -140,6 +140,15 @@ def test_subpixel_upsample_conv(gpu_lib, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_wide_head(gpu_lib, dtype):
+    """VAE mid-block attention shape (1 head x 512 over a 64x64 plane) and ragged variants on the real DMA path."""
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=1, d=512, tq=4096, tk=4096)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=1, d=512, tq=1089, tk=1089, spike=True)      # 33x33 plane
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=9, heads=1, d=512, tq=200, tk=77)                     # groups > 8: XCD slots
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_attention_dma_large(gpu_lib, dtype):
     oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=5, tq=4096, tk=4096)     # UNet level 0 self-attention
     oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=2, tq=130, tk=325, spike=True)
