@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
                         }
                         mt = fmaxf(mt, sacc[f][kf][r]);
                     }
-                mt = fmaxf(mt, __shfl_xor(mt, 16));
-                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                mt = quad_max(mt);
                 const float m_new = fmaxf(m_run[f], mt);
                 const float alpha = exp2_fast((m_run[f] - m_new) * c2);
                 const float mc = m_new * c2;
@@ -343,9 +342,11 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
                         psum += pv;
                     }
                 l_run[f] = l_run[f] * alpha + psum;             // per-lane partial; quads are summed once at the end
-                m_run[f] = m_new;
+                if (wave_any(m_new != m_run[f])) {              // wave-uniform: rescale only when some running max moved
 #pragma unroll
-                for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
+                    for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
+                }
+                m_run[f] = m_new;
             }
         };
         if (need_mask) softmax(std::true_type{});
@@ -544,8 +545,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
                     sacc[f][kf][r] = sv;
                     mt = fmaxf(mt, sv);
                 }
-            mt = fmaxf(mt, __shfl_xor(mt, 16));
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            mt = quad_max(mt);
             const float m_new = fmaxf(m_run[f], mt);
             alpha[f] = exp2_fast(m_run[f] - m_new);
             float psum = 0.f;

@@ -185,6 +185,30 @@ __device__ __forceinline__ void widen_pair(f32x4 a, f32x4 b, float v[8]) {
     }
 }
 
+// max / sum over the four lanes {l, l^16, l^32, l^48} that hold one MFMA column: two VALU swaps
+// (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two ds_bpermute round trips through the LDS queue
+#ifdef I2I_EMU
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ float quad_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // {rows 0,0,2,2}, {rows 1,1,3,3}
+    const float m = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, m);
+    r = __builtin_amdgcn_permlane32_swap(w, w, false, false);            // {lo half, lo half}, {hi half, hi half}
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, m);
+    r = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
