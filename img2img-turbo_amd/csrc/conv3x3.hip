@@ -549,8 +549,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                     S += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 0];
                     Q += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 1];
                 }
-            const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
-            float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
+            // one slot per (image, spatial tile[, parity of the sub-pixel form]): every workgroup owns its own
+            constexpr int NPAR = SUBPIX ? 4 : 1;
+            const int tile_in_img = ((ty0 / TH) * tiles_x + tx0 / TW) * NPAR + (SUBPIX ? pa * 2 + pb : 0);
+            float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y * NPAR) + tile_in_img) * groups + g) * 2;
             out[0] = S;
             out[1] = Q;
         }
@@ -593,11 +595,15 @@ void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     }
 }
 
+// tile rows of the sub-pixel upsampler launch (16 with 8 waves when that still fills the chip, else 8 with 4 waves)
+int subpix_th(const i2i_igemm_params& p) {
+    return (p.hin >= 16 && p.nimg * ((p.hin + 15) / 16) * ((p.win + 15) / 16) * ((p.N + 127) / 128) >= 128) ? 16 : 8;
+}
+
 template <typename T>
 int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
     if (p.subpix) {      // sub-pixel upsampler: weights are [4 parities][N][4*cin], tiles walk the source plane
-        if (p.hin >= 16 && p.nimg * ((p.hin + 15) / 16) * ((p.win + 15) / 16) * ((p.N + 127) / 128) >= 128)
-            return launch_halo<T, 16, 128, 4, 2, 2, 2, true>(p, s);
+        if (subpix_th(p) == 16) return launch_halo<T, 16, 128, 4, 2, 2, 2, true>(p, s);
         return launch_halo<T, 8, 128, 2, 2, 2, 2, true>(p, s);
     }
     const int cfg = halo_cfg(p);
@@ -630,7 +636,7 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.wo < TW || p.ho < 8) return false;
     if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
     if ((p.up_h || p.up_w) && (p.ups != 1 || p.subpix)) return false;
-    if (p.subpix && (p.ups != 1 || p.win < TW || p.hin < 8 || p.ldb != 4 * (p.c0 + p.c1) || p.gn_part)) return false;
+    if (p.subpix && (p.ups != 1 || p.win < TW || p.hin < 8 || p.ldb != 4 * (p.c0 + p.c1))) return false;
     if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
     return true;
 }
@@ -639,6 +645,11 @@ bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
 int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     if (!conv3x3_halo_eligible(p, dtype) || p.out_f32 || groups < 1 || p.N % groups || p.N % 4) return 0;
     const int cpg = p.N / groups;
+    if (p.subpix) {      // tiles walk the SOURCE plane, four parity workgroups (= four slots) per tile; 64 channels per wave
+        if (cpg % 4 || 64 % cpg) return 0;
+        const int th = subpix_th(p);
+        return 4 * ((p.win + TW - 1) / TW) * ((p.hin + th - 1) / th);
+    }
     int th, bn, wtn;
     halo_cfg_geometry(halo_cfg(p), &th, &bn, &wtn);
     if (cpg % 4 || wtn % cpg) return 0;

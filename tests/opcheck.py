@@ -300,7 +300,7 @@ def check_latent_ops(lib, device, dtype, *, n=2, h=4, w=6, seed=0, r=0.4):
     return err
 
 
-def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, groups=8, tile=10, res=True, seed=0):
+def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, groups=8, tile=10, res=True, seed=0, subpix=False):
     """3x3 conv whose epilogue emits the GroupNorm partial sums of its OUTPUT (gn_part), finished by
     gn_stats(finalize_only): the (scale, shift) pairs must match statistics taken from the stored tensor."""
     g = torch.Generator().manual_seed(seed)
@@ -312,17 +312,23 @@ def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, 
     beta = 0.1 * torch.randn(cout, generator=g)
     x0 = nhwc(x, dtype).to(device)
     wp = pack_conv_weight(wt, dtype).to(device)
-    out = torch.full((n, h, w, cout), float("nan"), dtype=dtype, device=device)
+    ho, wo = (2 * h, 2 * w) if subpix else (h, w)
+    if subpix:      # Upsample2D in sub-pixel form: the partial sums cover the 2h x 2w OUTPUT, four parity workgroups per tile
+        from img2img_turbo_amd.packer import subpixel_weights
+        wp = subpixel_weights(wt).reshape(4 * cout, 4 * cin).to(dtype).contiguous().to(device)
+        r = torch.randn(n, cout, ho, wo, generator=g) if res else None
+    out = torch.full((n, ho, wo, cout), float("nan"), dtype=dtype, device=device)
     rd = nhwc(r, dtype).to(device) if res else None
     bdev = b.to(device)      # keep alive: the op only holds raw pointers
-    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=h, wo=w, ks=3, stride=1, pad=1, N=cout, bias=bdev, res=rd, tile=tile)
+    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=3, stride=1, pad=1, ups=1 if subpix else 0, N=cout, bias=bdev,
+                       res=rd, tile=tile, subpix=1 if subpix else 0)
     parts = lib.igemm_gn_parts(p, O.DT[dtype], groups)
     assert parts > 0, "kernel declined GroupNorm partials"
     part = torch.full((n * parts * groups * 2,), float("nan"), device=device)
     p.gn_part, p.gn_part_groups = part.data_ptr(), groups
     ss = torch.full((n, cout, 2), float("nan"), device=device)
     gd, bd = gamma.to(device), beta.to(device)
-    op2, p2 = O.gn_stats(None, gd, bd, part, ss, nimg=n, hw=h * w, groups=groups, eps=1e-5, nparts=parts, c0=cout, ld0=cout, finalize_only=1)
+    op2, p2 = O.gn_stats(None, gd, bd, part, ss, nimg=n, hw=ho * wo, groups=groups, eps=1e-5, nparts=parts, c0=cout, ld0=cout, finalize_only=1)
     prog = K.Program()
     prog.add(opcode, O.DT[dtype], p)
     prog.add(op2, O.DT[dtype], p2)

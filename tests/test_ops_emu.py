@@ -187,6 +187,14 @@ def test_conv_epilogue_groupnorm_partials(emu_lib, cfg, dtype):
     oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=1, cin=64, cout=192, h=16, w=16, groups=12, tile=cfg, res=False)  # cpg 16, 2 n-tiles
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_subpixel_upsampler_groupnorm_partials(emu_lib, dtype):
+    """Upsample2D in sub-pixel form emits the next GroupNorm's partial sums: four parity workgroups per source tile,
+    ragged source plane, two channel tiles."""
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=2, cin=64, cout=64, h=12, w=20, groups=8, subpix=True)
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=1, cin=64, cout=192, h=16, w=16, groups=12, subpix=True, res=False)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_subpixel_upsample_conv(emu_lib, dtype):
     """Upsample2D in sub-pixel form (4 parity 2x2 convs over the source plane, tap weights pre-summed) against

@@ -139,6 +139,13 @@ def test_subpixel_upsample_conv(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_subpixel_upsampler_groupnorm_partials(gpu_lib, dtype):
+    oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=40, w=52, groups=32, subpix=True)        # 8-row tiles, ragged
+    oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=4, cin=256, cout=256, h=64, w=64, groups=32, subpix=True, res=False)  # 16-row tiles
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_attention_wide_head(gpu_lib, dtype):
     """VAE mid-block attention shape (1 head x 512 over a 64x64 plane) and ragged variants on the real DMA path."""
