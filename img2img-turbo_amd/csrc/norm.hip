@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
     const int gl = tid % gpb, sl = tid / gpb;
     if (sl < nsl) {
         float S = 0.f, Q = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 4
         for (int part = sl; part < p.nparts; part += nsl) {
-            const float* in = p.partial + (((int64_t)img * p.nparts + part) * p.groups + g0 + gl) * 2;
-            S += in[0];
-            Q += in[1];
+            const f32x2 v = *(const f32x2*)(p.partial + (((int64_t)img * p.nparts + part) * p.groups + g0 + gl) * 2);
+            S += v[0];
+            Q += v[1];
         }
         red[(sl * gpb + gl) * 2 + 0] = S;
         red[(sl * gpb + gl) * 2 + 1] = Q;
@@ -381,6 +383,10 @@ int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
     int gpb = p.groups;                            // groups per block: 8 when that divides, else all (<= 256)
     if (p.groups % 8 == 0) gpb = 8;
     else if (p.groups % 4 == 0) gpb = 4;
+    // conv epilogues hand over thousands of parts per image (2048 at 512x512): fewer groups per block = more blocks and
+    // a shorter serial chain per thread (8 parts instead of 64); the summation order stays a function of the shape only
+    if (p.nparts >= 1024) gpb = 1;
+    else if (p.nparts >= 256 && p.groups % 2 == 0) gpb = 2;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256), (size_t)gpb * 8 + (size_t)(256 / gpb) * gpb * 8, s, p, gpb);
     return i2i::check_launch("gn_finalize");
 }

@@ -257,6 +257,14 @@ def test_attention_wide_head(emu_lib, dtype):
     oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, d=512, tq=130, tk=64)
 
 
+def test_gn_finalize_many_parts(emu_lib):
+    """Finalize with hundreds / thousands of parts per image (what 512x512 conv epilogues hand over): the launcher
+    switches to 2 and then 1 group per block."""
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=64, groups=8, h=24, w=20, nparts=300, n=2)     # gpb = 2
+    oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, c0=128, groups=32, h=40, w=32, nparts=1100, n=1)  # gpb = 1
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, c0=24, groups=3, h=24, w=20, nparts=300, n=1)     # odd group count: stays at 3 per block
+
+
 def test_dma_igemm_narrow_input_conv(emu_lib):
     """VAE conv_in shape class: 3 -> 8 padded input channels, several taps per K step (per-chunk tap decode)."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=3, cout=40, h=9, w=12, tile=20)
