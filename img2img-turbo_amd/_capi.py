@@ -137,7 +137,7 @@ class Library:
     """One loaded libi2i_turbo.so.  ``path`` defaults to the in-tree product build."""
 
     def __init__(self, path=None):
-        path = path or DEFAULT_LIB
+        path = path or os.environ.get("I2I_LIB") or DEFAULT_LIB      # I2I_LIB: an experiment build (csrc/build.py --tag)
         if not os.path.exists(path):
             raise I2IError(
                 "HIP kernel library not found at %s -- build it with `python __graft_entry__.py` "

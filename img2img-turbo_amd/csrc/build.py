@@ -25,11 +25,11 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+def _compile(src, force, bdir="build", defs=()):
+    obj = os.path.join(HERE, bdir, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        cmd = ["hipcc"] + FLAGS + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -38,21 +38,27 @@ def _compile(src, force):
     return obj
 
 
-def build(force=False, jobs=None):
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+def build(force=False, jobs=None, tag=None, defs=()):
+    """tag/defs: an EXPERIMENT build next to the product one (libi2i_turbo_<tag>.so, objects in build_<tag>/), e.g.
+    ``build.py --tag glds_asm --defs=-DI2I_GLDS_ASM=1``; load it with I2I_LIB=<path> (img2img_turbo_amd._capi)."""
+    bdir = "build" + ("_" + tag if tag else "")
+    lib = LIB if not tag else os.path.join(HERE, "libi2i_turbo_%s.so" % tag)
+    os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        objs = list(ex.map(lambda s: _compile(s, force, bdir, defs), SOURCES))
+    if force or _stale(lib, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", type=int, default=None)
+    ap.add_argument("--tag", default=None, help="experiment build: libi2i_turbo_<tag>.so")
+    ap.add_argument("--defs", default="", help="extra hipcc flags of the experiment build, e.g. -DI2I_GLDS_ASM=1")
     a = ap.parse_args()
-    print(build(a.force, a.j))
+    print(build(a.force, a.j, a.tag, a.defs.split()))

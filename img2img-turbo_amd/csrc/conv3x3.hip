@@ -128,6 +128,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     }
     const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
     const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
+    // pixel pitches in bytes, pinned in VGPRs: left to itself hipcc re-reads the selected kernarg field with an
+    // s_load_dword + lgkmcnt(0) in every tap window (scalar-cache latency on the critical path of each step)
+    // (I2I_GLDS_ASM experiment build only, together with the hidden LDS-DMA: not yet measured on hardware)
+    unsigned ld0_b = (unsigned)p.lda0 * (unsigned)sizeof(T), ld1_b = (unsigned)p.lda1 * (unsigned)sizeof(T);
+#if defined(I2I_GLDS_ASM) && !defined(I2I_EMU)
+    asm volatile("" : "+v"(ld0_b), "+v"(ld1_b));
+#endif
 
     // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3),
     // physical chunk lane&7, i.e. source chunk (lane&7) ^ swz(row).  Rows past N are clamped (their
@@ -163,7 +170,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
         const int ci = slab * CK;                                       // wave-uniform source select
         const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
+#ifdef I2I_GLDS_ASM
+        const unsigned ldb = ci < p.c0 ? ld0_b : ld1_b;
+#else
         const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
+#endif
         const unsigned pix = (hpix[j] == ~0u) ? 0u : hpix[j];
         const unsigned voff = pix * ldb + (unsigned)kc * 16u;
         if (hidden) gload16_uncounted(rh[j], base, voff);
@@ -219,6 +230,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #pragma unroll
     for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
     wait_vmcnt<0>();
+    // I2I_GLDS_ASM build: retire these loads in hipcc's own bookkeeping on EVERY path, here: their consumers below sit in
+    // per-lane conditionals, and a load the compiler still considers pending on the skipped path gets a vmcnt wait at the
+    // first reuse of its register -- inside the slab loop, draining the (then invisible) DMA ring there
+#ifdef I2I_GLDS_ASM
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+#endif
     lds_barrier();
     halo_store_all();
     lds_barrier();
