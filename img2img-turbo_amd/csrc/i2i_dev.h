@@ -120,6 +120,7 @@ __device__ __forceinline__ int up_src(int i, int in, int up, int ups) {
 __device__ __forceinline__ void wait_lgkm0() {}
 template <int N> __device__ __forceinline__ void wait_vmcnt() {}
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) { emu::global_load_lds16(g, lds_wave_base); }
+__device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) { emu::global_load_lds16(sbase + voff, lds_wave_base); }
 #else
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -137,11 +138,22 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
+// same, source = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: one address VGPR instead of two
+__device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ub), "s"(dst) : "memory");
+}
 #else
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+__device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) { glds16(sbase + voff, lds_wave_base); }
 #endif
 #endif
 // A 16-byte global load hipcc does NOT count (cdna_hip_programming.md 5.7 form (ii)): beside an LDS-DMA pipeline
