@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of the hidden LDS-DMA experiment build (csrc/build.py --tag glds_asm --defs=-DI2I_GLDS_ASM=1; see DESIGN.md
+# A/B of the hidden LDS-DMA experiment build (csrc/build.py --tag glds_asm --defs="-DI2I_GLDS_ASM=1 -DI2I_GEMM_GNPART=1"; see DESIGN.md
 # "first experiments of the next round"): op parity on the real DMA paths, per-op rates, then the bench line, each
 # against the product library.  Run on the GPU box from the repo root; writes gpurun_out/exp_glds_asm.txt.
 EXP=img2img-turbo_amd/csrc/libi2i_turbo_glds_asm.so
 O=gpurun_out/exp_glds_asm.txt; mkdir -p gpurun_out; : > $O
-[ -f $EXP ] || python img2img-turbo_amd/csrc/build.py --tag glds_asm --defs=-DI2I_GLDS_ASM=1 >> $O 2>&1
+[ -f $EXP ] || python img2img-turbo_amd/csrc/build.py --tag glds_asm --defs="-DI2I_GLDS_ASM=1 -DI2I_GEMM_GNPART=1" >> $O 2>&1
 echo "== parity (experiment library)" >> $O
 I2I_LIB=$EXP timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -x -q >> $O 2>&1
 for lib in product exp; do

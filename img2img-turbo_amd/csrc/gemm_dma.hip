@@ -224,7 +224,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     // outputs with an even fragment count are widened to 8 consecutive n per lane (widen_pair, 16-byte stores)
     // Returns the number of store instructions this wave is GUARANTEED to have issued (0 = unknown): the persistent
     // stream adds it to its counted vmcnt so the next barrier does not wait for the stores to be acknowledged.
+#ifdef I2I_GLDS_ASM
+    // experiment build: lane ids enter the epilogue through an opaque copy, so hipcc recomputes the per-lane output offsets
+    // per tile instead of hoisting them out of the persistent tile loop into ~60 registers (the loop then spills)
+    auto epilogue_body = [&](int m0, int n0, int slot, int lr, int lq) __attribute__((always_inline)) -> int {
+#else
     auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
+#endif
     const bool exact = m0 + BM <= p.M && n0 + BN <= p.N;
     const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
     const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
@@ -286,6 +292,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     }
     const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0) &&
                       (((c_off | r_off) & 7) == 0) && (((uintptr_t)p.res & 15) == 0);
+#ifdef I2I_GEMM_GNPART
+    // GroupNorm partial sums of the stored output (next layer's norm), as in conv3x3.hip: per lane and 4-channel quad,
+    // then 16 rows (shuffles) -> wave (LDS) -> workgroup -> one slot per (image, row tile, group).  Wide path only (host check).
+    const bool do_stats = p.gn_part != nullptr;
+    float gs[FN], gq[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+#endif
     if (wide) {
         if constexpr (PERM) {
             // residual chunks first, all in flight together (the compiler cannot hoist them over the stores itself)
@@ -332,8 +346,58 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
                     *(chunk_t*)((T*)p.c + c_off + (int64_t)m * p.ldc + n) = o;
+#ifdef I2I_GEMM_GNPART
+                    if (do_stats) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float f = to_f32<T>(o[r]);
+                            gs[2 * jp + (r >> 2)] += f; gq[2 * jp + (r >> 2)] += f * f;
+                        }
+                    }
+#endif
                 }
             }
+#ifdef I2I_GEMM_GNPART
+            if (do_stats) {
+                // quad index inside the wave's channel span of accumulator slot (2*jp + h): channel = (2*jp + (lq>>1))*16 + (lq&1)*8 + 4*h
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int msk = 1; msk < 16; msk <<= 1) { gs[j] += __shfl_xor(gs[j], msk); gq[j] += __shfl_xor(gq[j], msk); }
+                float* st = (float*)(i2i_smem + bias_base + (PERSIST ? 4096 : 1024));      // [NW][FN*4 quads][2]
+                lds_barrier();
+                if (lr == 0) {
+#pragma unroll
+                    for (int jp = 0; jp < FN / 2; ++jp)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int quad = (((2 * jp + (lq >> 1)) * 16 + (lq & 1) * 8) >> 2) + h2;
+                            st[(wave * FN * 4 + quad) * 2 + 0] = gs[2 * jp + h2];
+                            st[(wave * FN * 4 + quad) * 2 + 1] = gq[2 * jp + h2];
+                        }
+                }
+                lds_barrier();
+                const int groups = p.gn_part_groups, cpg = p.N / groups;
+                const int ng_tile = BN / cpg;
+                const int g = n0 / cpg + tid;
+                if (tid < ng_tile && g < groups) {
+                    const int c0w = tid * cpg;
+                    const int wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
+                    float S = 0.f, Q = 0.f;
+                    for (int wmm = 0; wmm < WM; ++wmm)
+                        for (int q = q0; q < q0 + nq; ++q) {
+                            S += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 0];
+                            Q += st[((wmm * WN + wnn) * FN * 4 + q) * 2 + 1];
+                        }
+                    const int hw = p.ho * p.wo, parts = hw / BM;
+                    const int img = m0 / hw, part = (m0 - img * hw) / BM;
+                    float* out = p.gn_part + (((int64_t)img * parts + part) * groups + g) * 2;
+                    out[0] = S;
+                    out[1] = Q;
+                }
+                // (a persistent stream reuses the scratch: the barrier ahead of the next tile's writes orders them after these reads)
+            }
+#endif
         }
         return exact ? FM * (FN / 2) : 0;
     }
@@ -383,6 +447,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     }
     return 0;
     };
+#ifdef I2I_GLDS_ASM
+    auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
+        int lr_o = lr, lq_o = lq;
+        asm volatile("" : "+v"(lr_o), "+v"(lq_o));
+        return epilogue_body(m0, n0, slot, lr_o, lq_o);
+    };
+#endif
 
     // One K step.  `cur` = ring slot of the step (runtime: ONE copy of the step in the instruction stream).  The DMA
     // batch of step s+3 (B_s) goes out right after P_s and is waited for at P_{s+2} with a counted vmcnt that leaves
@@ -505,6 +576,12 @@ unsigned persist_wgs(unsigned resident) {
     return e ? (unsigned)atoi(e) : resident;
 }
 
+#ifdef I2I_GEMM_GNPART
+constexpr size_t GNP_LDS = 2048;      // [NW <= 8][FN*4 <= 16 quads][2] floats of GroupNorm partial scratch
+#else
+constexpr size_t GNP_LDS = 0;
+#endif
+
 template <typename T, int BM, int BN, int WM, int WN, int MINW>
 int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
     const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
@@ -515,13 +592,13 @@ int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
     const int per = (nk + (int)nsp - 1) / (int)nsp;
     constexpr size_t STAGE = (size_t)(BM + BN) * 128;
     // persistent stream when the tiles outnumber the resident workgroups (one z, whole K per tile)
-    constexpr unsigned OCC = (unsigned)((160 * 1024) / (3 * STAGE + 4096)), RES = 256u * (OCC < 1 ? 1u : OCC);
+    constexpr unsigned OCC = (unsigned)((160 * 1024) / (3 * STAGE + 4096 + GNP_LDS)), RES = 256u * (OCC < 1 ? 1u : OCC);
     const unsigned wgs = persist_wgs(RES);
     if (nsp == 1 && p.zcount == 1 && wgs > 0 && tiles >= 2 * wgs) {     // measured: 1.5 rounds gain nothing (tail imbalance)
-        hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, true>), dim3(wgs), dim3(WM * WN * 64), 3 * STAGE + 4096, s, p);
+        hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, true>), dim3(wgs), dim3(WM * WN * 64), 3 * STAGE + 4096 + GNP_LDS, s, p);
         return i2i::check_launch("igemm_dma(persistent)");
     }
-    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * STAGE + 1024;      // + the bias slot
+    const size_t smem = (size_t)(per < 3 ? (per < 1 ? 1 : per) : 3) * STAGE + 1024 + GNP_LDS;      // + the bias slot (+ GroupNorm partial scratch)
     hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, MINW, false>), dim3(tiles, (unsigned)p.zcount, nsp), dim3(WM * WN * 64), smem, s, p);
     int rc = i2i::check_launch("igemm_dma");
     if (rc != I2I_OK || nsp == 1) return rc;
@@ -531,14 +608,18 @@ int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
 }
 
 // tile ids 20..29 (i2i_igemm_params.tile): 20 = auto
-template <typename T>
-int launch_dma_t(const i2i_igemm_params& p, hipStream_t s) {
+int dma_cfg(const i2i_igemm_params& p) {
     int cfg = p.tile;
     if (cfg == 0 || cfg == 20) {
         if (p.M <= 2048) cfg = (p.N <= 64) ? 24 : 23;          // measured (profiles/): BM = 64 for the small-M shapes
         else if (p.N <= 64) cfg = 22;
         else cfg = 25;
     }
+    return cfg;
+}
+template <typename T>
+int launch_dma_t(const i2i_igemm_params& p, hipStream_t s) {
+    const int cfg = dma_cfg(p);
     switch (cfg) {
         case 21: return launch_dma<T, 128, 128, 2, 2, 2>(p, s);   // 96 KiB ring, 1 workgroup / CU
         case 22: return launch_dma<T, 128, 64, 2, 2, 2>(p, s);    // 72 KiB ring, 2 workgroups / CU
@@ -571,6 +652,29 @@ bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.splitk > 1 && (!p.ws || p.zcount > 1 || p.geglu)) return false;
     if (p.act_out && p.geglu) return false;
     return true;
+}
+// GroupNorm partial-sum slots per image the LDS-DMA igemm writes for this op (0 = it cannot): 16-bit wide-store path, one
+// z, no split-K / GEGLU, row tiles that do not straddle images, channels-per-group a multiple of 4 dividing a wave's span.
+int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
+#ifdef I2I_GEMM_GNPART
+    if (!igemm_dma_eligible(p, dtype) || dtype == I2I_F32 || p.out_f32 || p.geglu || p.splitk > 1 || p.zcount > 1) return 0;
+    if (groups < 1 || p.N % groups || p.N % 8 || p.ldc % 8 || (p.res && p.ldr % 8) || ((uintptr_t)p.res & 15)) return 0;
+    int bm, wtn;
+    switch (dma_cfg(p)) {
+        case 21: bm = 128; wtn = 64; break;
+        case 22: bm = 128; wtn = 32; break;
+        case 23: bm = 64; wtn = 64; break;
+        case 24: bm = 64; wtn = 32; break;
+        case 25: bm = 256; wtn = 64; break;
+        default: return 0;
+    }
+    const int cpg = p.N / groups, hw = p.ho * p.wo;
+    if (cpg % 4 || wtn % cpg || hw % bm) return 0;
+    return hw / bm;
+#else
+    (void)p; (void)dtype; (void)groups;
+    return 0;
+#endif
 }
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     switch (dtype) {

@@ -23,6 +23,7 @@ namespace i2i {
 bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype);   // conv3x3.hip
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s);
 int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
+int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.hip
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
@@ -297,7 +298,7 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
-    if (p.gn_part && !i2i::conv3x3_halo_gn_parts(p, dtype, p.gn_part_groups))
+    if (p.gn_part && !i2i_igemm_gn_parts(&p, dtype, p.gn_part_groups))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: gn_part requested but this op cannot produce GroupNorm partials (query i2i_igemm_gn_parts first)");
     if (p.act_out && (!i2i::igemm_dma_eligible(p, dtype) || i2i::conv3x3_halo_eligible(p, dtype)))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: act_out is implemented by the LDS-DMA igemm only (no GN prologue, aligned output, not a halo conv)");
@@ -323,6 +324,9 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     if (!pp) return 0;
     i2i_igemm_params p = *pp;
     if (p.zcount < 1) p.zcount = 1;
-    if (p.tile != 0 && !(p.tile >= 10 && p.tile <= 19) && !(p.tile >= 30 && p.tile <= 39)) return 0;
-    return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
+    // mirrors the routing of i2i_igemm: halo conv when eligible and not forced elsewhere, else the LDS-DMA igemm
+    const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
+    if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
+    if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
+    return 0;
 }

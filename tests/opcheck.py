@@ -300,19 +300,20 @@ def check_latent_ops(lib, device, dtype, *, n=2, h=4, w=6, seed=0, r=0.4):
     return err
 
 
-def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, groups=8, tile=10, res=True, seed=0, subpix=False):
+def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, groups=8, tile=10, res=True, seed=0, subpix=False,
+                       ks=3, stride=1, skip_if_declined=False):
     """3x3 conv whose epilogue emits the GroupNorm partial sums of its OUTPUT (gn_part), finished by
     gn_stats(finalize_only): the (scale, shift) pairs must match statistics taken from the stored tensor."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
     b = torch.randn(cout, generator=g) * 0.1
-    r = torch.randn(n, cout, h, w, generator=g) if res else None
+    r = torch.randn(n, cout, h // stride, w // stride, generator=g) if res else None
     gamma = 1 + 0.1 * torch.randn(cout, generator=g)
     beta = 0.1 * torch.randn(cout, generator=g)
     x0 = nhwc(x, dtype).to(device)
     wp = pack_conv_weight(wt, dtype).to(device)
-    ho, wo = (2 * h, 2 * w) if subpix else (h, w)
+    ho, wo = (2 * h, 2 * w) if subpix else (h // stride, w // stride)
     if subpix:      # Upsample2D in sub-pixel form: the partial sums cover the 2h x 2w OUTPUT, four parity workgroups per tile
         from img2img_turbo_amd.packer import subpixel_weights
         wp = subpixel_weights(wt).reshape(4 * cout, 4 * cin).to(dtype).contiguous().to(device)
@@ -320,9 +321,12 @@ def check_conv_gn_part(lib, device, dtype, *, n=2, cin=64, cout=64, h=16, w=16, 
     out = torch.full((n, ho, wo, cout), float("nan"), dtype=dtype, device=device)
     rd = nhwc(r, dtype).to(device) if res else None
     bdev = b.to(device)      # keep alive: the op only holds raw pointers
-    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=3, stride=1, pad=1, ups=1 if subpix else 0, N=cout, bias=bdev,
+    opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=1 if subpix else 0, N=cout, bias=bdev,
                        res=rd, tile=tile, subpix=1 if subpix else 0)
     parts = lib.igemm_gn_parts(p, O.DT[dtype], groups)
+    if parts == 0 and skip_if_declined:
+        import pytest
+        pytest.skip("this build of the library does not emit GroupNorm partials for this op (compile-time gated feature)")
     assert parts > 0, "kernel declined GroupNorm partials"
     part = torch.full((n * parts * groups * 2,), float("nan"), device=device)
     p.gn_part, p.gn_part_groups = part.data_ptr(), groups

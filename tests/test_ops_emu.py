@@ -257,6 +257,19 @@ def test_attention_wide_head(emu_lib, dtype):
     oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, d=512, tq=130, tk=64)
 
 
+@pytest.mark.parametrize("wgs", [0, 2])
+def test_dma_igemm_epilogue_groupnorm_partials(emu_lib, wgs, monkeypatch):
+    """Next-round feature (compiled into the emulator build only): the LDS-DMA igemm epilogue emits the
+    GroupNorm partial sums of its output -- 1x1 skip conv with residual, stride-2 downsampler, two channel tiles, one tile
+    per workgroup and the persistent stream."""
+    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
+    if emu_lib.igemm_gn_parts is None:
+        pytest.skip("library without i2i_igemm_gn_parts")
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)            # cpg 4, BM 64
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=256, h=48, w=48, groups=32, tile=20, ks=1, res=False)  # BM 256, 2 n-tiles
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=32, w=32, groups=8, tile=20, stride=2)          # stride-2 gather
+
+
 def test_gn_finalize_many_parts(emu_lib):
     """Finalize with hundreds / thousands of parts per image (what 512x512 conv epilogues hand over): the launcher
     switches to 2 and then 1 group per block."""

@@ -139,6 +139,16 @@ def test_subpixel_upsample_conv(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
+def test_dma_igemm_epilogue_groupnorm_partials(gpu_lib):
+    """GroupNorm partial sums from the LDS-DMA igemm epilogue (I2I_GEMM_GNPART builds; skipped on a library without it):
+    VAE skip-conv / conv_in / downsampler shapes, persistent stream included."""
+    kw = dict(skip_if_declined=True, tile=20)
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=256, w=256, groups=32, ks=1, **kw)           # persistent, 2 n-tiles
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=128, w=128, groups=32, stride=2, res=False, **kw)
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=4, cin=512, cout=512, h=32, w=32, groups=32, ks=1, **kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_subpixel_upsampler_groupnorm_partials(gpu_lib, dtype):
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=40, w=52, groups=32, subpix=True)        # 8-row tiles, ragged
