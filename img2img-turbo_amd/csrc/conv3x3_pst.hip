@@ -1,54 +1,28 @@
-// Halo-tiled 3x3 stride-1 pad-1 implicit-GEMM convolution for gfx950 -- the kernel that carries ~87 % of
-// the forward's FLOPs (every resnet conv and upsampler conv of the VAE and UNet; F.conv2d in
-// diffusers ResnetBlock2D / Upsample2D, with the preceding F.group_norm + F.silu, F.interpolate(nearest 2x)
-// and torch.cat folded into the operand staging, bias / residual into the epilogue).
-//
-// Workgroup = TH x 16 output pixels of ONE image x BN output channels; WM x WN waves, each owning
-// TH/WM tile rows x BN/WN channels as 16x16 fp32 MFMA fragments.  K loop = (channel slab of 64 halves /
-// 32 floats) x (9 taps):
-//   * A operand (pixels): the (TH+2) x 18 input halo of the slab is staged ONCE per slab
-//     (global_load_dwordx4 -> GroupNorm affine + SiLU in registers -> ds_write_b128) and the nine taps
-//     read their fragments from that one LDS image at shifted rows; an m-fragment is one 16-pixel tile
-//     row, so tap (dy,dx) reads 16 consecutive 128-byte rows starting at (ty+dy)*18 + dx.  The XOR
-//     swizzle lds_chunk_off2 keeps those reads conflict-free for every start row.
-//   * B operand (weights [N][9*Cin], LoRA merged): streamed by LDS-DMA (global_load_lds_dwordx4) into a
-//     double buffer, one [BN][64] slab per tap, issued one tap ahead; the per-lane SOURCE address carries
-//     the swizzle, the LDS destination is lane-linear.  No VGPRs, no ds_write, no VALU.
-//   * one raw s_barrier per tap (plus one per slab for the halo hand-over); vmcnt is only drained where
-//     the DMA result is needed.  LDS = halo (single buffer: the next slab's halo waits in registers) +
-//     2 weight buffers = 72.5 KiB for the 16x16x128 tile, so two workgroups share a CU and cover each
-//     other's prologue / slab hand-over / epilogue.
-//   * MFMA operands are issued swapped (A = weights, B = pixels) so an accumulator lane holds 4
-//     CONSECUTIVE channels of one pixel: bias / residual / store move as 8-byte (16-byte fp32) vectors.
-// Nearest-2x upsampling is an index map while staging the halo (Upsample2D never materialises).
+// Persistent-stream variant of the halo-tiled 3x3 convolution (conv3x3.hip): a workgroup runs its tiles as ONE continuous
+// sequence of (slab, tap) steps.  The weight DMA ring and the halo prefetch of the "following slab" cross tile borders, so a
+// tile's first slab is staged under the previous tile's last taps and its epilogue runs with the next tile's weights already
+// in flight -- the prologue / epilogue share of a tile (about one slab time: DESIGN.md section 9) overlaps instead of adding.
+// EXPERIMENT BUILD ONLY (-DI2I_PST_CONV=1; also compiled into the CPU emulator build, which checks its logic): not part of the
+// product library until it has been measured on hardware.  3x3 stride 1 pad 1, no sub-pixel form, single halo buffer.
+#ifdef I2I_PST_CONV
+#include <cstdlib>
 #include "i2i_dev.h"
 #include "launch.h"
 
 namespace {
 
 constexpr int TW = 16;
-template <int V> struct ic { static constexpr int value = V; };   // compile-time int passed through generic lambdas
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {   // f(ic<0>{}) ... f(ic<N-1>{})
+template <int V> struct ic { static constexpr int value = V; };
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
         static_for<N - 1>(f);
         f(ic<N - 1>{});
     }
 }
 
-// PD = pixel-fragment prefetch distance in row groups (2 or 3); MINW = min waves per SIMD for the register allocator.
-// SUBPIX: sub-pixel form of "nearest-2x upsample then 3x3 conv" (diffusers Upsample2D): output pixel (2y+a, 2x+b)
-// only ever sees a 2x2 neighbourhood of the SOURCE plane, so each output parity (a,b) is a 2x2 convolution of
-// the source with the tap weights pre-summed (packer.subpixel_weights) -- 4/9 of the MFMA work, no index map.
-// A workgroup then owns TH x 16 SOURCE positions of one parity: halo (TH+1) x 17, 4 taps per slab, 2-deep weight
-// ring (4 % 3 != 0), outputs scattered to (2y+a, 2x+b).
-// DBH: double-buffered halo.  The next slab's halo is transformed and stored into the OTHER halo image one chunk
-// per tap, interleaved with the MFMAs of the current slab (chunk loaded in tap t's window, stored in tap t+1's), so
-// the serial hand-over (two barriers + the whole GroupNorm/SiLU pass with the matrix pipe idle) disappears and
-// only ~2 chunks are live in registers.  The LDS this costs is paid with a 2-deep weight ring (buffer = step
-// parity, toggled at run time because 9 taps is odd): (2 x halo + 2 x weights) of the 8x16x128 tile = 79 KiB,
-// still two workgroups per CU.
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX, bool DBH>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i2i_igemm_params p) {
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2i_igemm_params p) {
+    constexpr bool SUBPIX = false, DBH = false;
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int CK = 8 * EPC;                      // channels per slab: 64 (16-bit) / 32 (f32)
@@ -76,17 +50,22 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // plane the tiles walk over: the output plane, or the SOURCE plane for the sub-pixel form
-    const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
+    const int pl_h = p.ho, pl_w = p.wo;
     const int tiles_x = (pl_w + TW - 1) / TW, tiles_y = (pl_h + TH - 1) / TH;
     const int ntn = (p.N + BN - 1) / BN;
-    const int tn = bid % ntn; bid /= ntn;
-    int pa = 0, pb = 0;                              // output parity (row, column) of this workgroup
-    if (SUBPIX) { pa = (bid >> 1) & 1; pb = bid & 1; bid >>= 2; }
-    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
-    const int ty0 = (bid % tiles_y) * TH;
-    const int img = bid / tiles_y;
-    const int n0 = tn * BN;
+    const int ntiles = tiles_x * tiles_y * p.nimg * ntn;
+    const int G = gridDim.x;                         // workgroup `bid` runs tiles bid, bid + G, bid + 2G, ...
+    constexpr int pa = 0, pb = 0;
+    // current tile (the one being multiplied / stored) -- changes at every tile border
+    int tx0, ty0, img, n0;
+    auto decode = [&](int t, int& tx, int& ty, int& im, int& nn) __attribute__((always_inline)) {
+        const int tn = t % ntn; t /= ntn;
+        tx = (t % tiles_x) * TW; t /= tiles_x;
+        ty = (t % tiles_y) * TH;
+        im = t / tiles_y;
+        nn = tn * BN;
+    };
+    decode(bid, tx0, ty0, img, n0);
 
     const T* __restrict__ a0 = (const T*)p.a0;
     const T* __restrict__ a1 = (const T*)p.a1;
@@ -106,76 +85,96 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     int hcur = 0;                                    // DBH: halo image / constant block of the slab being multiplied
 
     // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
-    // One 32-bit pixel index per chunk (inside image `img`; ~0 = zero padding); the byte offset
-    // pixel * ld + kc*16 is formed at the load against a wave-uniform base (SGPR base + 32-bit VGPR offset).
-    unsigned hpix[HPT];
+    // One 32-bit pixel index per chunk (inside its image; ~0 = zero padding).  They describe the FOLLOWING slab (f_*): the
+    // same tile while it has slabs left, else the workgroup's next tile -- all halo work after the prologue (loads, GN
+    // constants, hand-over store) is for the following slab, the current one is read from LDS only.
+    unsigned f_hpix[HPT];
+    auto fill_hpix = [&](unsigned* hp_out, int tx, int ty) __attribute__((always_inline)) {
+        int t_ = tid;            // opaque: nothing lane-derived in here may be hoisted out of the tile loop into registers
+#ifndef I2I_EMU
+        asm volatile("" : "+v"(t_));
+#endif
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) {
-        const int hp = (tid >> 3) + j * (NT / 8);
-        unsigned pix = ~0u;
-        if (hp < HALO) {
-            const int hy = hp / HW2, hx = hp - hy * HW2;
-            if (SUBPIX) {                                              // source coordinates of halo pixel (hy, hx)
-                const int iy = ty0 + hy + pa - 1, ix = tx0 + hx + pb - 1;
-                if ((unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win) pix = (unsigned)(iy * p.win + ix);
-            } else {
-                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;       // coordinates in the (upsampled) input plane
+        for (int j = 0; j < HPT; ++j) {
+            const int hp = (t_ >> 3) + j * (NT / 8);
+            unsigned pix = ~0u;
+            if (hp < HALO) {
+                const int hy = hp / HW2, hx = hp - hy * HW2;
+                const int iy = ty + hy - 1, ix = tx + hx - 1;       // coordinates in the (upsampled) input plane
                 if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up)
                     pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
             }
+            hp_out[j] = pix;
+            __builtin_amdgcn_sched_barrier(0);     // one chunk at a time: this also runs mid-stream with every accumulator live
         }
-        hpix[j] = pix;
-    }
-    const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
-    const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
-    // pixel pitches in bytes, pinned in VGPRs: left to itself hipcc re-reads the selected kernarg field with an
-    // s_load_dword + lgkmcnt(0) in every tap window (scalar-cache latency on the critical path of each step)
-    // (I2I_GLDS_ASM experiment build only, together with the hidden LDS-DMA: not yet measured on hardware)
+    };
+    fill_hpix(f_hpix, tx0, ty0);
+    auto img_base = [&](const T* a, int lda, int im) __attribute__((always_inline)) -> const char* {
+        return (const char*)a + (int64_t)im * p.hin * p.win * lda * (int)sizeof(T);
+    };
+    const char* f_img0 = img_base(a0, p.lda0, img);
+    const char* f_img1 = img_base(a1, p.lda1, img);
+    int f_img = img;
+#ifdef I2I_GLDS_ASM
     unsigned ld0_b = (unsigned)p.lda0 * (unsigned)sizeof(T), ld1_b = (unsigned)p.lda1 * (unsigned)sizeof(T);
-#if defined(I2I_GLDS_ASM) && !defined(I2I_EMU)
+#ifndef I2I_EMU
     asm volatile("" : "+v"(ld0_b), "+v"(ld1_b));
+#endif
 #endif
 
     // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3),
     // physical chunk lane&7, i.e. source chunk (lane&7) ^ swz(row).  Rows past N are clamped (their
     // accumulator columns are never stored).
-    unsigned b_voff[BPW];     // per-lane BYTE offset inside the weight matrix (N*ldb*sizeof(T) < 2^32)
+    unsigned b_voff[BPW], f_bvoff[BPW];     // per-lane BYTE offset inside the weight matrix (N*ldb*sizeof(T) < 2^32)
+    auto fill_bvoff = [&](unsigned* out, int nn) __attribute__((always_inline)) {
+        int l_ = lane;
+#ifndef I2I_EMU
+        asm volatile("" : "+v"(l_));
+#endif
 #pragma unroll
-    for (int q = 0; q < BPW; ++q) {
-        const int pc = wave + q * NW;
-        const int row = pc * 8 + (lane >> 3);
-        int n = n0 + row;
-        n = n < p.N ? n : p.N - 1;
-        b_voff[q] = (unsigned)(n * p.ldb + (((lane & 7) ^ lds_swz2(row)) * EPC)) * (unsigned)sizeof(T);
-    }
-    auto b_dma = [&](int slab, int tap, int buf) __attribute__((always_inline)) {
+        for (int q = 0; q < BPW; ++q) {
+            const int pc = wave + q * NW;
+            const int row = pc * 8 + (l_ >> 3);
+            int n = nn + row;
+            n = n < p.N ? n : p.N - 1;
+            out[q] = (unsigned)(n * p.ldb + (((l_ & 7) ^ lds_swz2(row)) * EPC)) * (unsigned)sizeof(T);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    fill_bvoff(b_voff, n0);
+#pragma unroll
+    for (int q = 0; q < BPW; ++q) f_bvoff[q] = b_voff[q];
+    // weights of (slab, tap): the current tile's rows, or (fol) the following slab's tile's rows
+    auto b_dma_any = [&](const unsigned* voff, int slab, int tap, int buf) __attribute__((always_inline)) {
         const char* src = (const char*)(bw + (tap * cin + slab * CK));      // wave-uniform part of the address
 #pragma unroll
         for (int q = 0; q < BPW; ++q) {
             const int pc = wave + q * NW;
-            if (NPIECE % NW == 0 || pc < NPIECE) glds16(src + b_voff[q], Bs + buf * BN * 128 + pc * 1024);
+            if (NPIECE % NW == 0 || pc < NPIECE) glds16(src + voff[q], Bs + buf * BN * 128 + pc * 1024);
         }
     };
+    auto b_dma = [&](int slab, int tap, int buf) __attribute__((always_inline)) { b_dma_any(b_voff, slab, tap, buf); };
+    auto b_dma_f = [&](int slab, int tap, int buf) __attribute__((always_inline)) { b_dma_any(f_bvoff, slab, tap, buf); };
 
     chunk_t rh[HPT];
 
     // GroupNorm (scale, shift) of the slab's CK channels: CK*8 bytes by LDS-DMA into Ss (one partial piece)
     auto ss_dma = [&](int slab, int sbuf) __attribute__((always_inline)) {
         if (wave == 0 && lane < CK / 2)
-            glds16(p.gn_ss + ((int64_t)img * cin + slab * CK) * 2 + lane * 4, Ss + sbuf * 512);
+            glds16(p.gn_ss + ((int64_t)f_img * cin + slab * CK) * 2 + lane * 4, Ss + sbuf * 512);
     };
     // One 16-byte load per call, ALWAYS and branch-free (padding lanes read pixel 0 of the image and are zeroed when
     // the halo is stored): the counted vmcnt waits rely on every wave issuing the same number of VMEM operations
     // per window.  `hidden`: the load is invisible to hipcc's waitcnt bookkeeping (see gload16_uncounted).
     auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
         const int ci = slab * CK;                                       // wave-uniform source select
-        const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
+        const char* base = ci < p.c0 ? f_img0 + ci * (int)sizeof(T) : f_img1 + (ci - p.c0) * (int)sizeof(T);
 #ifdef I2I_GLDS_ASM
         const unsigned ldb = ci < p.c0 ? ld0_b : ld1_b;
 #else
         const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
 #endif
-        const unsigned pix = (hpix[j] == ~0u) ? 0u : hpix[j];
+        const unsigned pix = (f_hpix[j] == ~0u) ? 0u : f_hpix[j];
         const unsigned voff = pix * ldb + (unsigned)kc * 16u;
         if (hidden) gload16_uncounted(rh[j], base, voff);
         else rh[j] = *(const chunk_t*)(base + voff);
@@ -184,8 +183,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     auto halo_store_one = [&](int j, int hbuf, const float* ssr) __attribute__((always_inline)) {
         const int hp = (tid >> 3) + j * (NT / 8);
         if (hp < HALO) {
-            chunk_t c = (hpix[j] != ~0u) ? rh[j] : zero_chunk<T>();
-            if (has_gn && hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
+            chunk_t c = (f_hpix[j] != ~0u) ? rh[j] : zero_chunk<T>();
+            if (has_gn && f_hpix[j] != ~0u) {    // zero padding stays exactly zero (conv pads the ACTIVATED tensor)
                 float v[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = to_f32<T>(c[e]) * ssr[2 * e] + ssr[2 * e + 1];
@@ -319,10 +318,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     //   in steady state.
     constexpr int DMA_OPS = (NPIECE % NW == 0) ? BPW : 0;     // DMA instructions every wave issues per batch
     auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0; j += NTAPS) ++c; return c; };   // halo loads issued in tap t's window
-    auto step = [&](int slab, bool next_slab, auto tapc) __attribute__((always_inline)) {
+    // fslab: index of the FOLLOWING slab inside ITS tile (slab + 1, or 0 of the next tile; == slab when nothing follows)
+    auto step = [&](int slab, bool next_slab, int fslab, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         const bool more = tap < NTAPS - 1 || next_slab;   // another step follows
-        if (!DBH && tap == NTAPS - 2 && next_slab && has_gn) ss_dma(slab + 1, 0);   // Ss was last read at the previous hand-over
+        if (!DBH && tap == NTAPS - 2 && next_slab && has_gn) ss_dma(fslab, 0);   // Ss was last read at the previous hand-over
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (tap == 0) {                         // first step of a slab: the halo image is new
 #pragma unroll
@@ -375,14 +375,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         //    there is no next one, so the count per window never changes), then the DMA of B[s+3] into the buffer
         //    just released.  Halo first: the hand-over then waits with vmcnt(DMA_OPS) and leaves the DMA in flight.
         {
-            const int hs = next_slab ? slab + 1 : slab;
+            const int hs = fslab;
             if constexpr (tap < HPT) halo_load(hs, tap, true);
             if constexpr (tap + NTAPS < HPT) halo_load(hs, tap + NTAPS, true);
             if constexpr (tap + 2 * NTAPS < HPT) halo_load(hs, tap + 2 * NTAPS, true);
             static_assert(DBH || 3 * NTAPS >= HPT, "halo loads do not fit the taps of a slab");
         }
         if (tap + RING < NTAPS) b_dma(slab, tap + RING, tap % RING);
-        else if (next_slab) b_dma(slab + 1, tap + RING - NTAPS, tap % RING);
+        else if (next_slab) b_dma_f(fslab, tap + RING - NTAPS, tap % RING);
         }
         __builtin_amdgcn_sched_barrier(0);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
@@ -406,19 +406,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         }
     };
 
-    // first weights of the first step (every later step finds w0 preloaded by its predecessor)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);     // buffer 0 in both layouts
-    for (int slab = 0; slab < nslab; ++slab) {
-        const bool next_slab = slab + 1 < nslab;
-        static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, tc); });
-    }
-    // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
-    // destination registers -- hipcc does not know those registers have a write in flight.
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
-
+    // ---- epilogue of the CURRENT tile (tx0, ty0, img, n0); runs between two tiles of the stream with the next tile's halo
+    // already in Hs and its first weight slabs in flight, so its GroupNorm scratch lives behind the GN constant block
+    // (lane ids enter through an opaque copy: hipcc otherwise hoists every lane-derived piece of the output addressing out of
+    // the tile loop and the step pipeline spills)
+    auto epilogue_body = [&](int lr, int lq, int tid) __attribute__((always_inline)) {
     // ---- epilogue: alpha, bias, residual, store, GroupNorm partial sums of what was stored.
     // Lane (lr, lq) holds pixel (oy, tx0 + lr).  16-bit outputs with an even fragment count take the wide path:
     // fragment pairs are half-exchanged (widen_pair) so every lane stores 16 bytes = 8 consecutive channels;
@@ -450,6 +442,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                         rres[i][jp] = *(const chunk_t*)(res + m * p.ldr + (ok ? n : 0));
                     }
                 }
+                // retire the loads in hipcc's bookkeeping on every path (their consumers sit behind per-lane `continue`s): a load it
+                // still believes pending costs a vmcnt(0) at the first reuse of its register -- inside the next tile's steps
+#pragma unroll
+                for (int jp = 0; jp < FN / 2; ++jp)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) reg_fence(rres[i][jp]);
             }
 #pragma unroll
             for (int jp = 0; jp < FN / 2; ++jp) {
@@ -459,6 +457,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                 float bv[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) reg_fence(bv[r]);
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     float v[8];
@@ -496,6 +496,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             if (p.bias_mode == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) reg_fence(bv[r]);
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) { gs[j] += __shfl_xor(gs[j], m); gq[j] += __shfl_xor(gq[j], m); }
         lds_barrier();                                   // every wave is done with its fragments
-        float* st = (float*)i2i_smem;                    // [NW][FN*4 quads][2]
+        float* st = (float*)(Ss + 512);                  // [NW][FN*4 quads][2], behind the GN constants (Hs holds the next tile)
         if (lr == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -575,122 +577,99 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             out[1] = Q;
         }
     }
-}
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        int lr_o = lr, lq_o = lq, tid_o = tid;
+#ifndef I2I_EMU
+        asm volatile("" : "+v"(lr_o), "+v"(lq_o), "+v"(tid_o));
+#endif
+        epilogue_body(lr_o, lq_o, tid_o);
+    };
 
-template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false, bool DBH = false>
-int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
-    constexpr int KS = SUBPIX ? 2 : 3, RING = (SUBPIX || DBH) ? 2 : 3;
-    const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
-    const unsigned tiles = (unsigned)(((pl_w + TW - 1) / TW) * ((pl_h + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN)) * (SUBPIX ? 4u : 1u);
-    const size_t smem = ((DBH ? 2 : 1) * (TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + (DBH ? 1024 : 512);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW, SUBPIX, DBH>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
-    return i2i::check_launch("conv3x3_halo");
-}
-
-// tile ids (i2i_igemm_params.tile): 10 = auto; 11..19 force one configuration (tests / tuning)
-int halo_cfg(const i2i_igemm_params& p) {
-    int cfg = p.tile;
-    if (cfg == 0 || cfg == 10) {
-        const bool tall = p.ho >= 16;
-        if (p.N <= 16) cfg = 16;
-        else if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64)) cfg = tall ? 14 : 15;
-        else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles_bench_ops.log)
-        else if (p.N == 256 && p.c0 + p.c1 == 256 && p.ho * p.wo >= 128 * 128) cfg = 34;   // +6 % (profiles/r1_conv_bn256_bench_ops.log)
-        else cfg = (p.c0 + p.c1 <= 256) ? 17 : 13;
+    // ---- the stream ----
+    const int my_tiles = (ntiles - bid + G - 1) / G;
+    // first weights of the first step (every later step finds w0 preloaded by its predecessor, across tiles too)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const bool last_tile = ti + 1 == my_tiles;
+        for (int slab = 0; slab < nslab; ++slab) {
+            const bool in_tile_next = slab + 1 < nslab;
+            const bool next_slab = in_tile_next || !last_tile;
+            const int fslab = in_tile_next ? slab + 1 : (last_tile ? slab : 0);
+            if (!in_tile_next && !last_tile) {        // the following slab opens my next tile: its pixels, image and weight rows
+                int ftx, fty, fimg, fn0;
+                decode(bid + (ti + 1) * G, ftx, fty, fimg, fn0);
+                fill_hpix(f_hpix, ftx, fty);
+                f_img0 = img_base(a0, p.lda0, fimg);
+                f_img1 = img_base(a1, p.lda1, fimg);
+                f_img = fimg;
+                fill_bvoff(f_bvoff, fn0);
+            }
+            static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, fslab, tc); });
+        }
+        if (last_tile) {
+            // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
+            // destination registers -- hipcc does not know those registers have a write in flight.
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+        }
+        epilogue();
+        if (!last_tile) {                             // the following slab's tile becomes the current one
+            decode(bid + (ti + 1) * G, tx0, ty0, img, n0);
+#pragma unroll
+            for (int q = 0; q < BPW; ++q) b_voff[q] = f_bvoff[q];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    return cfg;
-}
-// (tile rows, channel tile, channels per wave) of a configuration
-void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
-    switch (cfg) {
-        case 11: case 19: *th = 16; *bn = 128; *wtn = 64; break;
-        case 12: case 18: case 32: *th = 16; *bn = 128; *wtn = 64; break;
-        case 13: case 17: case 31: case 33: case 43: case 47: *th = 8; *bn = 128; *wtn = 64; break;
-        case 14: *th = 16; *bn = 64; *wtn = 32; break;
-        case 34: *th = 8; *bn = 256; *wtn = 64; break;
-        case 15: *th = 8; *bn = 64; *wtn = 32; break;
-        default: *th = 8; *bn = 16; *wtn = 16; break;
-    }
 }
 
-// tile rows of the sub-pixel upsampler launch (16 with 8 waves when that still fills the chip, else 8 with 4 waves)
-int subpix_th(const i2i_igemm_params& p) {
-    return (p.hin >= 16 && p.nimg * ((p.hin + 15) / 16) * ((p.win + 15) / 16) * ((p.N + 127) / 128) >= 128) ? 16 : 8;
+// LDS: one halo image + 3 weight buffers + GN constants (512 B) + GN partial scratch (1 KiB)
+template <int TH, int BN> constexpr size_t pst_smem() { return (size_t)((TH + 2) * (TW + 2) + 3 * BN) * 128 + 512 + 1024; }
+
+unsigned pst_wgs(unsigned resident) {      // same test / A-B hook as the persistent igemm
+    const char* e = getenv("I2I_PERSIST_WGS");
+    return e ? (unsigned)atoi(e) : resident;
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW>
+int launch_pst(const i2i_igemm_params& p, hipStream_t s) {
+    const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN));
+    constexpr size_t smem = pst_smem<TH, BN>();
+    constexpr unsigned OCC = (unsigned)((160 * 1024) / smem);
+    unsigned wgs = pst_wgs(256u * (OCC < 1 ? 1u : OCC));
+    if (wgs == 0 || wgs > tiles) wgs = tiles;
+    hipLaunchKernelGGL((conv3x3_pst_kernel<T, TH, BN, WM, WN, PD, MINW>), dim3(wgs), dim3(WM * WN * 64), smem, s, p);
+    return i2i::check_launch("conv3x3_pst");
 }
 
 template <typename T>
-int launch_halo_t(const i2i_igemm_params& p, hipStream_t s) {
-    if (p.subpix) {      // sub-pixel upsampler: weights are [4 parities][N][4*cin], tiles walk the source plane
-        if (subpix_th(p) == 16) return launch_halo<T, 16, 128, 4, 2, 2, 2, true>(p, s);
-        return launch_halo<T, 8, 128, 2, 2, 2, 2, true>(p, s);
-    }
-    const int cfg = halo_cfg(p);
-    switch (cfg) {
-        case 11: return launch_halo<T, 16, 128, 2, 2, 2, 1>(p, s);   // 4 waves x (8 rows x 64 ch), 1 workgroup / CU
-        case 12: return launch_halo<T, 16, 128, 4, 2, 2, 2>(p, s);   // 8 waves x (4 rows x 64 ch), 1 workgroup / CU
-        case 13: return launch_halo<T, 8, 128, 2, 2, 2, 2>(p, s);    // 4 waves x (4 rows x 64 ch), 2 workgroups / CU
-        case 14: return launch_halo<T, 16, 64, 2, 2, 2, 2>(p, s);
-        case 15: return launch_halo<T, 8, 64, 2, 2, 2, 2>(p, s);
-        case 16: return launch_halo<T, 8, 16, 4, 1, 2, 2>(p, s);
-        case 17: return launch_halo<T, 8, 128, 2, 2, 3, 2>(p, s);    // as 13, prefetch distance 3
-        case 18: return launch_halo<T, 16, 128, 4, 2, 3, 2>(p, s);   // as 12, prefetch distance 3
-        case 19: return launch_halo<T, 16, 128, 2, 2, 3, 1>(p, s);   // as 11, prefetch distance 3
-        case 34: return launch_halo<T, 8, 256, 2, 4, 2, 2>(p, s);    // 8 waves x (4 rows x 64 ch): halo staged once per 256 channels
-        case 31: return launch_halo<T, 8, 128, 2, 2, 2, 2, false, true>(p, s);    // as 13, double-buffered halo + 2-deep ring
-        case 32: return launch_halo<T, 16, 128, 4, 2, 2, 2, false, true>(p, s);   // as 12, double-buffered halo
-        case 33: return launch_halo<T, 8, 128, 2, 2, 3, 2, false, true>(p, s);    // as 31, prefetch distance 3
-    }
-    return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3: unknown tile config %d", cfg);
+int launch_pst_t(const i2i_igemm_params& p, int cfg, hipStream_t s) {
+    (void)cfg;      // 43 = persistent form of tile 13; 47 (prefetch distance 3, tile 17) spills in the step pipeline: same kernel for now
+    return launch_pst<T, 8, 128, 2, 2, 2, 2>(p, s);
 }
 
 }  // namespace
 
 namespace i2i {
-// Eligibility: 3x3, stride 1, pad 1, slab-aligned channel counts, a plane at least one tile wide.
-bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype) {
-    const int ck = (dtype == I2I_F32) ? 32 : 64;
-    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2) return false;
-    if (p.c0 % ck || p.c1 % ck || (p.c0 + p.c1) < ck) return false;
-    if (p.wo < TW || p.ho < 8) return false;
-    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
-    if ((p.up_h || p.up_w) && (p.ups != 1 || p.subpix)) return false;
-    if (p.subpix && (p.ups != 1 || p.win < TW || p.hin < 8 || p.ldb != 4 * (p.c0 + p.c1))) return false;
-    if (p.ldc % 4 || (p.res && p.ldr % 4)) return false;
-    return true;
-}
-// GroupNorm partial-sum slots per image (= spatial tiles) the halo kernel writes for this op, 0 if it cannot:
-// needs dtype output, N % 4 == 0 and channels-per-group a multiple of 4 dividing the channels one wave owns.
-int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
-    if (!conv3x3_halo_eligible(p, dtype) || p.out_f32 || groups < 1 || p.N % groups || p.N % 4) return 0;
-    const int cpg = p.N / groups;
-    if (p.subpix) {      // tiles walk the SOURCE plane, four parity workgroups (= four slots) per tile; 64 channels per wave
-        if (cpg % 4 || 64 % cpg) return 0;
-        const int th = subpix_th(p);
-        return 4 * ((p.win + TW - 1) / TW) * ((p.hin + th - 1) / th);
-    }
-    int th, bn, wtn;
-    halo_cfg_geometry(halo_cfg(p), &th, &bn, &wtn);
-    if (cpg % 4 || wtn % cpg) return 0;
-    return ((p.wo + TW - 1) / TW) * ((p.ho + th - 1) / th);
-}
-#ifdef I2I_PST_CONV
-int conv3x3_pst(const i2i_igemm_params& p, int dtype, int cfg, hipStream_t s);    // conv3x3_pst.hip (experiment build)
-bool conv3x3_pst_worthwhile(const i2i_igemm_params& p);
-#endif
-int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s) {
-#ifdef I2I_PST_CONV
-    if (!p.subpix) {
-        const int cfg = halo_cfg(p);
-        if (cfg == 43 || cfg == 47) return conv3x3_pst(p, dtype, cfg, s);
-        if ((p.tile == 0 || p.tile == 10) && (cfg == 13 || cfg == 17) && conv3x3_pst_worthwhile(p))
-            return conv3x3_pst(p, dtype, cfg == 17 ? 47 : 43, s);
-    }
-#endif
+// tile ids 43 / 47: the 8x16x128 halo tile (prefetch distance 2 / 3) as a persistent stream
+int conv3x3_pst(const i2i_igemm_params& p, int dtype, int cfg, hipStream_t s) {
     switch (dtype) {
-        case I2I_F32: return launch_halo_t<float>(p, s);
-        case I2I_BF16: return launch_halo_t<__bf16>(p, s);
-        case I2I_F16: return launch_halo_t<_Float16>(p, s);
+        case I2I_F32: return launch_pst_t<float>(p, cfg, s);
+        case I2I_BF16: return launch_pst_t<__bf16>(p, cfg, s);
+        case I2I_F16: return launch_pst_t<_Float16>(p, cfg, s);
     }
-    return fail(I2I_ERR_BAD_ARG, "conv3x3: bad dtype");
+    return fail(I2I_ERR_BAD_ARG, "conv3x3_pst: bad dtype");
+}
+// workgroups of a persistent launch (0 = not worth it: fewer than two tiles per resident workgroup)
+bool conv3x3_pst_worthwhile(const i2i_igemm_params& p) {
+    const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + 7) / 8) * p.nimg * ((p.N + 127) / 128));
+    const unsigned wgs = pst_wgs(256u * (unsigned)((160 * 1024) / pst_smem<8, 128>()));
+    return wgs > 0 && tiles >= 2 * wgs;
 }
 }  // namespace i2i
+#endif  // I2I_PST_CONV

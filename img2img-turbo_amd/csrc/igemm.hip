@@ -304,7 +304,7 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: act_out is implemented by the LDS-DMA igemm only (no GN prologue, aligned output, not a halo conv)");
     if (p.subpix && !i2i::conv3x3_halo_eligible(p, dtype))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need the halo conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
-    const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
+    const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 49);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)
@@ -325,7 +325,7 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     i2i_igemm_params p = *pp;
     if (p.zcount < 1) p.zcount = 1;
     // mirrors the routing of i2i_igemm: halo conv when eligible and not forced elsewhere, else the LDS-DMA igemm
-    const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
+    const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 49);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
     if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
     return 0;

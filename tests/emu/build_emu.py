@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "attention.hip", "capi.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_pst.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "attention.hip", "capi.hip"]
 OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
          "-Wno-unused-function", "-Wno-unknown-attributes",
          # next-round kernel features that are compile-time gated out of the product build until measured on hardware
          # (DESIGN.md section 9): their LOGIC is exercised here
-         "-DI2I_GEMM_GNPART=1"]
+         "-DI2I_GEMM_GNPART=1", "-DI2I_PST_CONV=1"]
 
 
 def _stale(out, deps):
