@@ -288,6 +288,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 }
             }
         }
+        if (exact && FN >= 2) note_vmem(FM * (FN / 2));      // (emulator's async model: the stores the next waits count)
         return (exact && FN >= 2) ? FM * (FN / 2) : 0;
     }
     const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0) &&
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
             }
 #endif
         }
+        if (exact) note_vmem(FM * (FN / 2));
         return exact ? FM * (FN / 2) : 0;
     }
 #pragma unroll

@@ -117,11 +117,13 @@ __device__ __forceinline__ int up_src(int i, int in, int up, int ups) {
 // counted waits; __syncthreads() would drain the DMA queue with vmcnt(0) at every barrier).
 // The CPU emulator (tests/emu, I2I_EMU) executes copies synchronously, so the waits are no-ops there.
 #ifdef I2I_EMU
+__device__ __forceinline__ void note_vmem(int n) { emu::vmem_note(n); }    // n compiler-visible VMEM ops a counted wait relies on
 __device__ __forceinline__ void wait_lgkm0() {}
-template <int N> __device__ __forceinline__ void wait_vmcnt() {}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { emu::vmem_wait(N); }      // retires queued copies in the async model
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) { emu::global_load_lds16(g, lds_wave_base); }
 __device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) { emu::global_load_lds16(sbase + voff, lds_wave_base); }
 #else
+__device__ __forceinline__ void note_vmem(int) {}
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // global_load_lds_dwordx4: 16 bytes per lane, global address per lane, LDS destination = wave-uniform base
@@ -162,7 +164,10 @@ __device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void
 // before its first use; between load and fence the destination must not be touched (keep the load unconditional,
 // no phi).  sbase must be provably wave-uniform (SGPR pair), voff a 32-bit byte offset.
 #ifdef I2I_EMU
-template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) { dst = *(const C*)(sbase + voff); }
+template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) {
+    if (emu::vmem_async()) emu::vmem_defer(sbase + voff, &dst, (int)sizeof(C));      // lands at the wait that covers it
+    else dst = *(const C*)(sbase + voff);
+}
 template <typename C> __device__ __forceinline__ void reg_fence(C&) {}
 #else
 template <typename C> __device__ __forceinline__ void gload16_uncounted(C& dst, const char* sbase, unsigned voff) {

@@ -65,9 +65,11 @@ void* g_sched_sp = nullptr;
 const std::function<void()>* g_body = nullptr;
 
 void yield_to_sched() { emu_switch(&g_fib[g_cur].sp, g_sched_sp); }
+void retire_all_of_current();
 
 void fiber_main() {
     (*g_body)();
+    retire_all_of_current();                 // s_endpgm: everything still in flight lands
     Fiber& f = g_fib[g_cur];
     f.done = true;
     Wave& w = g_wave[g_cur / 64];
@@ -107,6 +109,28 @@ bool runnable(const Fiber& f, int t) {
 }  // namespace
 
 int lane_id() { return g_cur & 63; }
+
+// ---- asynchronous-memory model: one FIFO of pending copies per lane (see hip_emu.h)
+namespace {
+struct Pending { const void* src; void* dst; int bytes; };
+std::vector<Pending> g_pend[kMaxThreads];
+size_t g_pend_head[kMaxThreads];
+bool g_async = false;
+void pend_retire(int t, size_t keep) {
+    std::vector<Pending>& q = g_pend[t];
+    while (q.size() - g_pend_head[t] > keep) {
+        const Pending& e = q[g_pend_head[t]++];
+        if (e.bytes > 0) memcpy(e.dst, e.src, (size_t)e.bytes);
+    }
+    if (g_pend_head[t] == q.size()) { q.clear(); g_pend_head[t] = 0; }
+}
+}  // namespace
+bool vmem_async() { return g_async; }
+void vmem_defer(const void* src, void* dst, int bytes) { g_pend[g_cur].push_back({src, dst, bytes}); }
+void vmem_note(int n) { if (g_async) for (int i = 0; i < n; ++i) g_pend[g_cur].push_back({nullptr, nullptr, 0}); }
+int g_wait_bias = 0;     // I2I_EMU_WAIT_BIAS: added to every count (self-test of the model: > 0 must break the DMA kernels)
+void vmem_wait(int n) { if (g_async) pend_retire(g_cur, (size_t)(n + g_wait_bias < 0 ? 0 : n + g_wait_bias)); }
+namespace { void retire_all_of_current() { if (g_async) pend_retire(g_cur, 0); } }
 
 void wave_collective(const void* in, size_t in_bytes, void* out, size_t out_bytes,
                      void (*fn)(const char*, char*, void*), void* ctx) {
@@ -154,6 +178,13 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t sme
     }
     g_body = &body;
     g_nthreads = nt;
+    {
+        const char* e = getenv("I2I_EMU_ASYNC");
+        g_async = e && atoi(e) != 0;
+        const char* b = getenv("I2I_EMU_WAIT_BIAS");
+        g_wait_bias = b ? atoi(b) : 0;
+        for (int t = 0; t < nt; ++t) { g_pend[t].clear(); g_pend_head[t] = 0; }
+    }
     blockDim = block;
     gridDim = grid;
     for (unsigned bz = 0; bz < grid.z; ++bz)

@@ -57,6 +57,14 @@ void wave_collective(const void* in, size_t in_bytes, void* out, size_t out_byte
                      void (*fn)(const char* in_slots, char* out_slots, void* ctx), void* ctx);
 void block_barrier();
 int lane_id();
+// Asynchronous-memory model (I2I_EMU_ASYNC=1): LDS-DMA copies and the loads the kernels hide from the compiler are QUEUED per
+// lane and only performed by the s_waitcnt vmcnt(N) that retires them (oldest first, until N remain) -- the latest completion
+// the in-order vmcnt counter allows.  The default (everything completes at issue) is the earliest one.  A kernel that reads
+// DMA data before the wait that covers it, or waits with too large a count, passes the default run and fails this one.
+bool vmem_async();
+void vmem_defer(const void* src, void* dst, int bytes);   // a queued 16-byte (or smaller) copy
+void vmem_note(int n);                                     // n compiler-visible VMEM ops the kernel counts in its waits (no data)
+void vmem_wait(int n);                                     // s_waitcnt vmcnt(n)
 }  // namespace emu
 
 namespace emu {
@@ -114,7 +122,8 @@ static inline void permlane32_swap(float& a, float& b) {
 }
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; executed synchronously here.
 static inline void global_load_lds16(const void* g, void* lds_wave_base) {
-    memcpy((char*)lds_wave_base + 16 * lane_id(), g, 16);
+    if (vmem_async()) vmem_defer(g, (char*)lds_wave_base + 16 * lane_id(), 16);
+    else memcpy((char*)lds_wave_base + 16 * lane_id(), g, 16);
 }
 }  // namespace emu
 static inline void __builtin_amdgcn_s_setprio(int) {}

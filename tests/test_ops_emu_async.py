@@ -1,0 +1,79 @@
+"""The DMA kernels again under the emulator's ASYNCHRONOUS memory model (tests/emu/hip_emu.h, I2I_EMU_ASYNC=1): LDS-DMA copies
+and compiler-hidden loads are queued per lane and land only at the s_waitcnt vmcnt(N) that retires them -- the LATEST completion
+the in-order counter allows, where the default emulator run is the EARLIEST (everything lands at issue).  A hand-counted wait that
+is one operation too generous, or data consumed before the wait that covers it, passes the default run and fails here; the GPU
+then only has to confirm what both extreme schedules already agree on.  (Test infrastructure only; the product never loads it.)"""
+import pytest
+import torch
+
+import opcheck as oc
+
+
+@pytest.fixture
+def async_lib(emu_lib, monkeypatch):
+    monkeypatch.setenv("I2I_EMU_ASYNC", "1")
+    return emu_lib
+
+
+@pytest.mark.parametrize("cfg", [12, 13, 14, 16, 17, 18, 31, 34])
+def test_halo_conv_waits(async_lib, cfg):
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=20, w=24, gn=True, act=1, res=True, tile=cfg)   # 2 slabs: hand-over + ring wrap
+    oc.check_conv(async_lib, "cpu", torch.float32, n=1, cin=96, cout=40, h=9, w=17, tile=cfg)                                 # 3 slabs of 32
+
+
+def test_subpixel_and_partials_waits(async_lib):
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=12, w=20, ups=1, res=True, subpix=True)
+    oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=64, h=16, w=16, groups=8, tile=13)
+
+
+@pytest.mark.parametrize("wgs", [0, 1, 3])
+def test_dma_igemm_waits(async_lib, wgs, monkeypatch):
+    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
+    for cfg in (22, 23, 24, 25):
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=cfg)      # 5 K steps, ragged
+        oc.check_conv(async_lib, "cpu", torch.float16, n=2, cin=64, cout=136, h=16, w=16, ks=1, pad=0, tile=cfg)                 # 1 K step, exact tiles
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=72, h=12, w=10, stride=2, pad=1, tile=20)
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=72, h=4, w=4, res=True, tile=23, splitk=3)
+    oc.check_geglu(async_lib, "cpu", torch.bfloat16, tile=24, cff=128, rows=200)
+    oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
+
+
+def test_attention_waits(async_lib):
+    oc.check_attention(async_lib, "cpu", torch.bfloat16, batch=1, heads=2, tq=130, tk=325, spike=True)        # d=64 ring of 3, 6 key tiles
+    oc.check_attention(async_lib, "cpu", torch.float16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)    # wide head, double buffer
+
+
+@pytest.mark.parametrize("wgs", [1, 3])
+def test_persistent_halo_conv_waits(async_lib, wgs, monkeypatch):
+    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=72, h=20, w=40, gn=True, act=1, res=True, tile=43)
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)
+    oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=43)
+
+
+def test_model_is_sensitive_to_one_operation(async_lib, monkeypatch):
+    """Self-test of the model: every wait one operation too generous (I2I_EMU_WAIT_BIAS=1) must break the kernels."""
+    monkeypatch.setenv("I2I_EMU_WAIT_BIAS", "1")
+    with pytest.raises(AssertionError):
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=128, h=16, w=32, tile=13)
+    with pytest.raises(AssertionError):
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, tile=25)
+    with pytest.raises(AssertionError):
+        oc.check_attention(async_lib, "cpu", torch.bfloat16, batch=1, heads=1, tq=64, tk=325)
+
+
+@pytest.mark.slow
+def test_whole_forward_under_the_async_model(async_lib):
+    """The planned program end to end (tiny architecture, bf16: every DMA kernel in its real sequence) on the adversarial schedule."""
+    from oracle import TINY_UNET, TINY_VAE
+    from oracle.pipeline import pix2pix_forward
+    from oracle.synth import make_inputs, make_pix2pix_weights
+    from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
+    from img2img_turbo_amd.weights import GeneratorWeights
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    w = GeneratorWeights(mw.unet, mw.vae, mw.unet_arch, mw.vae_arch, mw.unet_scaling, mw.vae_scaling, mw.vae_b2a)
+    model = Pix2Pix_Turbo(weights=w, device="cpu", dtype=torch.bfloat16, lib=async_lib)
+    out = model(x, caption_enc=cap, eps=eps)
+    assert (out.float() - ref).abs().max().item() < 0.25
