@@ -164,7 +164,7 @@ def main():
            "dtype": a.dtype, "data": "synthetic (random-init weights of the SD-Turbo architecture + LoRA r8/r4, Bernoulli edge maps)",
            "config": {"workload": "pix2pix-turbo edge_to_image %s bs=%d/GPU %dx%d, deterministic path, hipGraph replay" % (a.dtype, B, a.size, a.size),
                       "global_batch": total, "parallelism": "dp%d (batch shards, replicated weights, RCCL gather of outputs)" % world,
-                      "arch": a.arch},
+                      "arch": a.arch, "kernel_library": os.path.basename(model.lib.path)},
            "baseline_note": "vs_baseline = value / 9.09 img/s (0.11 s per 512x512 image on A100, reference README.md:17)"}
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":
