@@ -522,7 +522,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
             // explicit software pipeline: fragment n = (kc = n>>1, kf = n&1) is read LOOK fragments before its MFMAs
 #ifdef I2I_GLDS_ASM
             int kb0 = kb[0];
+#ifndef I2I_EMU
             asm volatile("" : "+v"(kb0));        // opaque per tile: keeps hipcc from re-materialising all four bases in registers
+#endif
 #endif
             auto kread = [&](int n) __attribute__((always_inline)) -> chunk_t {
                 const int kc = n >> 1, kf = n & 1;

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 #ifdef I2I_GLDS_ASM
     auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
         int lr_o = lr, lq_o = lq;
+#ifndef I2I_EMU
         asm volatile("" : "+v"(lr_o), "+v"(lq_o));
+#endif
         return epilogue_body(m0, n0, slot, lr_o, lq_o);
     };
 #endif

@@ -26,6 +26,18 @@ def emu_lib():
 
 
 @pytest.fixture(scope="session")
+def emu_lib_next():
+    """Emulator twin of the EXPERIMENT build's source variants (-DI2I_GLDS_ASM=1: the inline asm itself is compiled out under
+    I2I_EMU, the C++ that differs around it -- addressing, read-ahead depth, fences -- is what gets checked)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from img2img_turbo_amd import _capi
+    lib = _capi.Library(build_emu.build(tag="next", extra=["-DI2I_GLDS_ASM=1"]))
+    assert lib.backend == "emu"
+    return lib
+
+
+@pytest.fixture(scope="session")
 def gpu_lib():
     """The product library on a real GPU; fails loudly (no fallback) if the HIP build is missing."""
     import torch

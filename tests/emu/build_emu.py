@@ -30,29 +30,33 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _cc(src_path, obj, lang_cxx):
+def _cc(src_path, obj, lang_cxx, extra=()):
     deps = [src_path, os.path.join(HERE, "hip_emu.h"), os.path.join(CSRC, "i2i_dev.h"), os.path.join(CSRC, "launch.h"),
             os.path.join(ROOT, "include", "i2i_turbo.h")]
     if _stale(obj, deps):
-        cmd = [CLANG] + FLAGS + (["-x", "c++"] if lang_cxx else []) + ["-c", src_path, "-o", obj]
+        cmd = [CLANG] + FLAGS + list(extra) + (["-x", "c++"] if lang_cxx else []) + ["-c", src_path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emu compile failed for %s:\n%s" % (src_path, r.stderr))
     return obj
 
 
-def build():
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    jobs = [(os.path.join(CSRC, s), os.path.join(HERE, "build", s.replace(".hip", ".emu.o")), True) for s in SOURCES]
-    jobs += [(os.path.join(HERE, "hip_emu.cpp"), os.path.join(HERE, "build", "hip_emu.o"), False),
-             (os.path.join(HERE, "runtime_emu.cpp"), os.path.join(HERE, "build", "runtime_emu.o"), False)]
+def build(tag=None, extra=()):
+    """tag/extra: a second emulator library with additional defines (the LOGIC of the experiment build's source variants,
+    e.g. tag="next", extra=["-DI2I_GLDS_ASM=1"]: its asm statements are compiled out under I2I_EMU, the C++ around them is not)."""
+    bdir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
+    out = OUT if not tag else os.path.join(bdir, "libi2i_turbo_emu_%s.so" % tag)
+    os.makedirs(bdir, exist_ok=True)
+    jobs = [(os.path.join(CSRC, s), os.path.join(bdir, s.replace(".hip", ".emu.o")), True, extra) for s in SOURCES]
+    jobs += [(os.path.join(HERE, "hip_emu.cpp"), os.path.join(bdir, "hip_emu.o"), False, extra),
+             (os.path.join(HERE, "runtime_emu.cpp"), os.path.join(bdir, "runtime_emu.o"), False, extra)]
     with cf.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(lambda j: _cc(*j), jobs))
-    if _stale(OUT, objs):
-        r = subprocess.run([CLANG, "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
+    if _stale(out, objs):
+        r = subprocess.run([CLANG, "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emu link failed:\n" + r.stderr)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -77,3 +77,18 @@ def test_whole_forward_under_the_async_model(async_lib):
     model = Pix2Pix_Turbo(weights=w, device="cpu", dtype=torch.bfloat16, lib=async_lib)
     out = model(x, caption_enc=cap, eps=eps)
     assert (out.float() - ref).abs().max().item() < 0.25
+
+
+# ---- the experiment build's source variants under both memory models ----
+@pytest.mark.parametrize("async_model", ["0", "1"])
+def test_experiment_build_variants(emu_lib_next, async_model, monkeypatch):
+    lib = emu_lib_next
+    monkeypatch.setenv("I2I_EMU_ASYNC", async_model)
+    oc.check_attention(lib, "cpu", torch.bfloat16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)       # one K base ^ (j << 6), read-ahead 2
+    oc.check_attention(lib, "cpu", torch.float16, batch=2, heads=1, d=512, tq=130, tk=64)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=64, cout=72, h=20, w=24, gn=True, act=1, res=True, tile=13)   # pitches pinned per source
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=12, w=20, ups=1, subpix=True)
+    monkeypatch.setenv("I2I_PERSIST_WGS", "2")
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=25)            # epilogue behind opaque lane ids
+    oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)                   # persistent halo conv
