@@ -317,9 +317,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
     //   leaves the batch issued after P_{s+1} in flight -- two full steps of latency cover, never vmcnt(0)
     //   in steady state.
     constexpr int DMA_OPS = (NPIECE % NW == 0) ? BPW : 0;     // DMA instructions every wave issues per batch
+    constexpr int NST = FM * (FN / 2);                        // 16-byte stores per wave of an exact tile's epilogue
     auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0; j += NTAPS) ++c; return c; };   // halo loads issued in tap t's window
     // fslab: index of the FOLLOWING slab inside ITS tile (slab + 1, or 0 of the next tile; == slab when nothing follows)
-    auto step = [&](int slab, bool next_slab, int fslab, auto tapc) __attribute__((always_inline)) {
+    // est: NST if the epilogue that ran just before this slab left NST counted stores behind (first slab of a tile), else 0
+    auto step = [&](int slab, bool next_slab, int fslab, int est, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         const bool more = tap < NTAPS - 1 || next_slab;   // another step follows
         if (!DBH && tap == NTAPS - 2 && next_slab && has_gn) ss_dma(fslab, 0);   // Ss was last read at the previous hand-over
@@ -336,7 +338,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
         //    tap 8 of the previous slab, whose halo loads the hand-over already waited for.
         if constexpr (RING == 3) {
             constexpr int nhp = (tap == 0) ? 0 : nh(tap - 1);
-            if (tap + 2 < NTAPS || next_slab) wait_vmcnt<DMA_OPS + nhp>();
+            // tile border: the previous tile's stores sit between the awaited batch and this window (tap 0: [B, stores],
+            // tap 1: [B, stores, window 0]); in-order vmcnt => they may stay in flight if they are counted
+            if (tap <= 1 && est && (tap + 2 < NTAPS || next_slab)) wait_vmcnt<DMA_OPS + nhp + (tap <= 1 ? NST : 0)>();
+            else if (tap + 2 < NTAPS || next_slab) wait_vmcnt<DMA_OPS + nhp>();
             else wait_vmcnt<nhp>();
         } else {
             wait_vmcnt<0>();                              // 2-deep ring: B[s+1] is the most recent batch
@@ -410,7 +415,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
     // already in Hs and its first weight slabs in flight, so its GroupNorm scratch lives behind the GN constant block
     // (lane ids enter through an opaque copy: hipcc otherwise hoists every lane-derived piece of the output addressing out of
     // the tile loop and the step pipeline spills)
-    auto epilogue_body = [&](int lr, int lq, int tid) __attribute__((always_inline)) {
+    // Returns the number of store instructions every wave is GUARANTEED to have issued (exact tile on the 16-byte path, else 0):
+    // the first two steps of the next tile add it to their counted vmcnt instead of waiting for the stores to be acknowledged.
+    auto epilogue_body = [&](int lr, int lq, int tid) __attribute__((always_inline)) -> int {
     // ---- epilogue: alpha, bias, residual, store, GroupNorm partial sums of what was stored.
     // Lane (lr, lq) holds pixel (oy, tx0 + lr).  16-bit outputs with an even fragment count take the wide path:
     // fragment pairs are half-exchanged (widen_pair) so every lane stores 16 bytes = 8 consecutive channels;
@@ -577,17 +584,22 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
             out[1] = Q;
         }
     }
+    const bool exact = ty0 + TH <= p.ho && tx0 + TW <= p.wo && n0 + BN <= p.N;
+    const int nst = (wide && exact) ? NST : 0;
+    note_vmem(nst);                                  // (emulator's asynchronous model: the stores the next waits count)
+    return nst;
     };
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    auto epilogue = [&]() __attribute__((always_inline)) -> int {
         int lr_o = lr, lq_o = lq, tid_o = tid;
 #ifndef I2I_EMU
         asm volatile("" : "+v"(lr_o), "+v"(lq_o), "+v"(tid_o));
 #endif
-        epilogue_body(lr_o, lq_o, tid_o);
+        return epilogue_body(lr_o, lq_o, tid_o);
     };
 
     // ---- the stream ----
     const int my_tiles = (ntiles - bid + G - 1) / G;
+    int est = 0;                                     // counted stores of the previous tile's epilogue (0 before the first tile)
     // first weights of the first step (every later step finds w0 preloaded by its predecessor, across tiles too)
 #pragma unroll
     for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
                 f_img = fimg;
                 fill_bvoff(f_bvoff, fn0);
             }
-            static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, fslab, tc); });
+            static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, fslab, slab == 0 ? est : 0, tc); });
         }
         if (last_tile) {
             // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_pst_kernel(const i2
 #pragma unroll
             for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
         }
-        epilogue();
+        est = epilogue();
         if (!last_tile) {                             // the following slab's tile becomes the current one
             decode(bid + (ti + 1) * G, tx0, ty0, img, n0);
 #pragma unroll

@@ -283,6 +283,7 @@ def test_persistent_halo_conv(emu_lib, cfg, wgs, monkeypatch):
     oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cin2=64, cout=40, h=9, w=23, gn=True, act=1, tile=cfg)           # concat sources
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=64, h=8, w=16, ups=1, tile=cfg)                           # upsample index map
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=cfg)                # epilogue partial sums
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=32, res=True, tile=cfg)                       # exact tiles (counted stores)
 
 
 def test_gn_finalize_many_parts(emu_lib):
