@@ -607,7 +607,7 @@ void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
         case 12: case 18: case 32: *th = 16; *bn = 128; *wtn = 64; break;
         case 13: case 17: case 31: case 33: case 43: case 47: *th = 8; *bn = 128; *wtn = 64; break;
         case 14: *th = 16; *bn = 64; *wtn = 32; break;
-        case 34: *th = 8; *bn = 256; *wtn = 64; break;
+        case 34: case 44: *th = 8; *bn = 256; *wtn = 64; break;
         case 15: *th = 8; *bn = 64; *wtn = 32; break;
         default: *th = 8; *bn = 16; *wtn = 16; break;
     }
@@ -675,15 +675,16 @@ int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
 }
 #ifdef I2I_PST_CONV
 int conv3x3_pst(const i2i_igemm_params& p, int dtype, int cfg, hipStream_t s);    // conv3x3_pst.hip (experiment build)
-bool conv3x3_pst_worthwhile(const i2i_igemm_params& p);
+bool conv3x3_pst_worthwhile(const i2i_igemm_params& p, int bn);
 #endif
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s) {
 #ifdef I2I_PST_CONV
     if (!p.subpix) {
         const int cfg = halo_cfg(p);
-        if (cfg == 43 || cfg == 47) return conv3x3_pst(p, dtype, cfg, s);
-        if ((p.tile == 0 || p.tile == 10) && (cfg == 13 || cfg == 17) && conv3x3_pst_worthwhile(p))
+        if (cfg == 43 || cfg == 44 || cfg == 47) return conv3x3_pst(p, dtype, cfg, s);
+        if ((p.tile == 0 || p.tile == 10) && (cfg == 13 || cfg == 17) && conv3x3_pst_worthwhile(p, 128))
             return conv3x3_pst(p, dtype, cfg == 17 ? 47 : 43, s);
+        if ((p.tile == 0 || p.tile == 10) && cfg == 34 && conv3x3_pst_worthwhile(p, 256)) return conv3x3_pst(p, dtype, 44, s);
     }
 #endif
     switch (dtype) {

@@ -661,7 +661,8 @@ int launch_pst(const i2i_igemm_params& p, hipStream_t s) {
 
 template <typename T>
 int launch_pst_t(const i2i_igemm_params& p, int cfg, hipStream_t s) {
-    (void)cfg;      // 43 = persistent form of tile 13; 47 (prefetch distance 3, tile 17) spills in the step pipeline: same kernel for now
+    if (cfg == 44) return launch_pst<T, 8, 256, 2, 4, 2, 2>(p, s);      // persistent form of tile 34 (8 waves, one workgroup per CU)
+    // 43 = persistent form of tile 13; 47 (prefetch distance 3, tile 17) spills in the step pipeline: same kernel for now
     return launch_pst<T, 8, 128, 2, 2, 2, 2>(p, s);
 }
 
@@ -678,9 +679,10 @@ int conv3x3_pst(const i2i_igemm_params& p, int dtype, int cfg, hipStream_t s) {
     return fail(I2I_ERR_BAD_ARG, "conv3x3_pst: bad dtype");
 }
 // workgroups of a persistent launch (0 = not worth it: fewer than two tiles per resident workgroup)
-bool conv3x3_pst_worthwhile(const i2i_igemm_params& p) {
-    const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + 7) / 8) * p.nimg * ((p.N + 127) / 128));
-    const unsigned wgs = pst_wgs(256u * (unsigned)((160 * 1024) / pst_smem<8, 128>()));
+bool conv3x3_pst_worthwhile(const i2i_igemm_params& p, int bn) {
+    const unsigned tiles = (unsigned)(((p.wo + TW - 1) / TW) * ((p.ho + 7) / 8) * p.nimg * ((p.N + bn - 1) / bn));
+    const size_t smem = bn == 256 ? pst_smem<8, 256>() : pst_smem<8, 128>();
+    const unsigned wgs = pst_wgs(256u * (unsigned)((160 * 1024) / smem));
     return wgs > 0 && tiles >= 2 * wgs;
 }
 }  // namespace i2i

@@ -270,7 +270,7 @@ def test_dma_igemm_epilogue_groupnorm_partials(emu_lib, wgs, monkeypatch):
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=32, w=32, groups=8, tile=20, stride=2)          # stride-2 gather
 
 
-@pytest.mark.parametrize("cfg,wgs", [(43, 1), (43, 3), (47, 2), (43, 0)])
+@pytest.mark.parametrize("cfg,wgs", [(43, 1), (43, 3), (47, 2), (43, 0), (44, 1), (44, 2)])
 def test_persistent_halo_conv(emu_lib, cfg, wgs, monkeypatch):
     """Next-round kernel (conv3x3_pst.hip, compiled into the emulator build only): the halo conv as a persistent stream --
     the following slab's halo / weights cross tile borders, the epilogue runs between tiles.  One, two and three slabs per

@@ -52,6 +52,9 @@ def test_persistent_halo_conv_waits(async_lib, wgs, monkeypatch):
     # exact tiles everywhere: the epilogue stores are COUNTED in the first two waits of the next tile (1 and 2 slabs per tile)
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=32, res=True, tile=43)
     oc.check_conv(async_lib, "cpu", torch.float16, n=1, cin=128, cout=256, h=24, w=32, gn=True, act=1, tile=43)
+    # the 8-wave 8x16x256 form (tile 44): exact and ragged channel tiles
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=32, res=True, tile=44)
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=328, h=20, w=24, gn=True, act=1, tile=44)
 
 
 def test_model_is_sensitive_to_one_operation(async_lib, monkeypatch):

@@ -155,6 +155,7 @@ def test_persistent_halo_conv(gpu_lib, wgs, monkeypatch):
         oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=4, cin=128, cout=200, h=96, w=80, gn=True, act=1, tile=43, seed=rep)
         oc.check_conv(gpu_lib, "cuda", torch.float16, n=2, cin=512, cout=256, h=64, w=64, gn=True, act=1, res=True, tile=43, seed=rep)
     oc.check_conv(gpu_lib, "cuda", torch.float32, n=2, cin=64, cout=128, h=40, w=52, tile=43)
+    oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=4, cin=256, cout=256, h=128, w=128, gn=True, act=1, res=True, tile=44)   # 8x16x256, 8 waves
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=64, w=64, groups=32, tile=43)
 
 
