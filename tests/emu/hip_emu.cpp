@@ -128,6 +128,11 @@ void pend_retire(int t, size_t keep) {
 bool vmem_async() { return g_async; }
 void vmem_defer(const void* src, void* dst, int bytes) { g_pend[g_cur].push_back({src, dst, bytes}); }
 void vmem_note(int n) { if (g_async) for (int i = 0; i < n; ++i) g_pend[g_cur].push_back({nullptr, nullptr, 0}); }
+int g_drop_barrier = 0;      // I2I_EMU_DROP_BARRIER=n: every thread skips its n-th barrier (self-test: the schedules must notice)
+int g_barrier_calls[kMaxThreads];
+int g_order = 0;
+bool g_skew = false;         // I2I_EMU_ORDER set: run-ahead scheduling (see launch)
+unsigned long long g_rng = 1;
 int g_wait_bias = 0;     // I2I_EMU_WAIT_BIAS: added to every count (self-test of the model: > 0 must break the DMA kernels)
 void vmem_wait(int n) { if (g_async) pend_retire(g_cur, (size_t)(n + g_wait_bias < 0 ? 0 : n + g_wait_bias)); }
 namespace { void retire_all_of_current() { if (g_async) pend_retire(g_cur, 0); } }
@@ -157,6 +162,7 @@ void wave_collective(const void* in, size_t in_bytes, void* out, size_t out_byte
 
 void block_barrier() {
     const int me = g_cur;
+    if (g_drop_barrier > 0 && ++g_barrier_calls[me] == g_drop_barrier) return;     // self-test knob: this barrier is "forgotten"
     g_block_arrived++;
     if (g_block_arrived == g_block_live) {
         g_block_arrived = 0;
@@ -183,6 +189,12 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t sme
         g_async = e && atoi(e) != 0;
         const char* b = getenv("I2I_EMU_WAIT_BIAS");
         g_wait_bias = b ? atoi(b) : 0;
+        const char* d = getenv("I2I_EMU_DROP_BARRIER");
+        g_drop_barrier = d ? atoi(d) : 0;
+        const char* o = getenv("I2I_EMU_ORDER");
+        g_order = o ? atoi(o) : 0;
+        g_skew = o != nullptr;
+        g_rng = 0x9E3779B97F4A7C15ull ^ (unsigned long long)g_order;
         for (int t = 0; t < nt; ++t) { g_pend[t].clear(); g_pend_head[t] = 0; }
     }
     blockDim = block;
@@ -199,20 +211,48 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t sme
                     g_wave[w].live = (nt - w * 64) < 64 ? (nt - w * 64) : 64;
                 }
                 g_block_gen = 0; g_block_arrived = 0; g_block_live = nt;
+                for (int t = 0; t < nt; ++t) g_barrier_calls[t] = 0;
                 // poison LDS so reads of unwritten bytes show up as NaNs / garbage
                 memset(i2i_smem, 0xFF, smem ? smem : 1);
                 int remaining = nt;
+                const int nwaves = (nt + 63) / 64;
                 while (remaining > 0) {
                     bool progress = false;
-                    for (int t = 0; t < nt; ++t) {
-                        Fiber& f = g_fib[t];
-                        if (!runnable(f, t)) continue;
-                        g_cur = t;
-                        threadIdx = f.tid;
-                        blockIdx = {bx, by, bz};
-                        emu_switch(&g_sched_sp, f.sp);
-                        progress = true;
-                        if (f.done) remaining--;
+                    // wave order of this sweep (I2I_EMU_ORDER): 0 ascending, 1 descending, n > 1 pseudo-random (seed n).  A fiber
+                    // runs until it blocks, so the order decides which wave races ahead between two barriers: a missing
+                    // barrier that the ascending order happens to hide shows up under another one.
+                    int order[kMaxThreads / 64];
+                    for (int w = 0; w < nwaves; ++w) order[w] = w;
+                    if (g_order == 1) for (int w = 0; w < nwaves; ++w) order[w] = nwaves - 1 - w;
+                    else if (g_order > 1)
+                        for (int w = nwaves - 1; w > 0; --w) {
+                            g_rng = g_rng * 6364136223846793005ull + 1442695040888963407ull;
+                            const int k = (int)((g_rng >> 33) % (unsigned)(w + 1));
+                            const int tmp = order[w]; order[w] = order[k]; order[k] = tmp;
+                        }
+                    // Each wave runs until it can go no further (all lanes blocked at a BLOCK barrier, or done) before the next one
+                    // starts: wave-level collectives (MFMA, shuffles) complete inside the inner loop, so the leading wave is a whole
+                    // barrier interval ahead of the others -- the widest skew real hardware can show between two barriers.  With
+                    // I2I_EMU_ORDER unset the classic lock-step sweep (one pass over all waves) is kept.
+                    for (int wi = 0; wi < nwaves; ++wi) {
+                        bool wave_progress = true;
+                        while (wave_progress) {
+                            wave_progress = false;
+                            for (int l = 0; l < 64; ++l) {
+                                const int t = order[wi] * 64 + l;
+                                if (t >= nt) continue;
+                                Fiber& f = g_fib[t];
+                                if (!runnable(f, t)) continue;
+                                g_cur = t;
+                                threadIdx = f.tid;
+                                blockIdx = {bx, by, bz};
+                                emu_switch(&g_sched_sp, f.sp);
+                                progress = true;
+                                wave_progress = true;
+                                if (f.done) remaining--;
+                            }
+                            if (!g_skew) break;            // lock-step mode: one pass per wave and sweep
+                        }
                     }
                     if (!progress) { fprintf(stderr, "emu: deadlock in block (%u,%u,%u)\n", bx, by, bz); abort(); }
                 }

@@ -98,3 +98,41 @@ def test_experiment_build_variants(emu_lib_next, async_model, monkeypatch):
     oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=25)            # epilogue behind opaque lane ids
     oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
     oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)                   # persistent halo conv
+
+
+# ---- barriers: run-ahead wave scheduling (I2I_EMU_ORDER): each wave runs a whole barrier interval ahead of the next one ----
+@pytest.mark.parametrize("order", ["0", "1", "7"])
+def test_barriers_under_wave_skew(emu_lib, order, monkeypatch):
+    """The emulator's default sweep advances all waves in lock step, which hides a missing barrier.  With I2I_EMU_ORDER set, a
+    wave runs until it blocks at a BLOCK barrier before the next wave starts (ascending / descending / shuffled leaders) -- on
+    top of the latest-completion memory model.  Every LDS pipeline again."""
+    monkeypatch.setenv("I2I_EMU_ORDER", order)
+    monkeypatch.setenv("I2I_EMU_ASYNC", "1")
+    lib = emu_lib
+    for cfg in (12, 13, 14, 17, 34):
+        oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=20, w=24, gn=True, act=1, res=True, tile=cfg)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=12, w=20, ups=1, res=True, subpix=True)
+    oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=64, h=16, w=16, groups=8, tile=13)
+    monkeypatch.setenv("I2I_PERSIST_WGS", "2")
+    for cfg in (22, 24, 25):
+        oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=cfg)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=128, cout=72, h=4, w=4, res=True, tile=23, splitk=3)
+    oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
+    oc.check_attention(lib, "cpu", torch.bfloat16, batch=1, heads=2, tq=130, tk=325, spike=True)
+    oc.check_attention(lib, "cpu", torch.float16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)
+    oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=32, res=True, tile=44)
+    oc.check_gn_stats(lib, "cpu", torch.bfloat16, c0=128, groups=32, h=40, w=32, nparts=1100, n=1)
+    oc.check_layernorm(lib, "cpu", torch.bfloat16)
+    oc.check_softmax(lib, "cpu", torch.bfloat16)
+
+
+def test_skew_notices_a_forgotten_barrier(emu_lib, monkeypatch):
+    """Self-test: with every thread's 5th barrier dropped (a K-step barrier of the pipelines) the run-ahead schedule must fail."""
+    monkeypatch.setenv("I2I_EMU_ORDER", "1")
+    monkeypatch.setenv("I2I_EMU_ASYNC", "1")
+    monkeypatch.setenv("I2I_EMU_DROP_BARRIER", "5")
+    with pytest.raises(AssertionError):
+        oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=128, h=16, w=32, tile=13)
+    with pytest.raises(AssertionError):
+        oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, tile=25)
