@@ -9,6 +9,14 @@
 // (cdna_hip_programming.md section 3).  This checks indexing, tiling, LDS layout and epilogue logic
 // bit-for-bit against the oracle on the CPU.  It says nothing about performance and is never loaded
 // by the product (img2img-turbo_amd/_capi.py loads only the hipcc-built library).
+//
+// Synchronisation is checked on adversarial schedules selected by environment variables (read per launch):
+//   I2I_EMU_ASYNC=1          LDS-DMA copies / hidden loads land only at the s_waitcnt vmcnt(N) that retires them (latest
+//                            completion the in-order counter allows; the default is the earliest: at issue)
+//   I2I_EMU_ORDER=0|1|n      run-ahead wave scheduling: a wave runs until it blocks at a block barrier before the next one
+//                            starts (ascending / descending / shuffled with seed n); unset = lock-step sweep
+//   I2I_EMU_WAIT_BIAS=k      self-test: every vmcnt wait k operations too generous  (the kernels must then fail)
+//   I2I_EMU_DROP_BARRIER=n   self-test: every thread skips its n-th barrier          (the kernels must then fail)
 #pragma once
 #include <cmath>
 #include <cstddef>
