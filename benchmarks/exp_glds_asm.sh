@@ -7,6 +7,8 @@ O=gpurun_out/exp_glds_asm.txt; mkdir -p gpurun_out; : > $O
 [ -f $EXP ] || python img2img-turbo_amd/csrc/build.py --tag glds_asm --defs="-DI2I_GLDS_ASM=1 -DI2I_GEMM_GNPART=1 -DI2I_PST_CONV=1" >> $O 2>&1
 echo "== parity (experiment library)" >> $O
 I2I_LIB=$EXP timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -x -q >> $O 2>&1
+echo "== end-to-end parity, tiny architecture + SD-Turbo 512 (experiment library)" >> $O
+I2I_LIB=$EXP timeout 600 python -m pytest tests/test_e2e_gpu.py -m gpu -x -q -s -k "tiny_pix2pix or full_sd_turbo" >> $O 2>&1
 # exp = everything; exp_nopst = experiment library with the persistent streams off (I2I_PERSIST_WGS=0: one tile per workgroup in
 # the halo conv AND the igemm), which isolates the hidden-DMA / counted-wait effect
 for lib in product exp exp_nopst; do
