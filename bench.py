@@ -1,18 +1,25 @@
-"""Headline benchmark: 512x512 images/s of the Pix2Pix_Turbo forward (BASELINE.json configs[1]:
-pix2pix-turbo edge_to_image, bf16, bs=8 per GPU) on N MI355X GPUs of one node.
+"""Headline benchmark: 512x512 images/s of the Pix2Pix_Turbo / CycleGAN_Turbo generator forward on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py                                    # BASELINE configs[1]: pix2pix-turbo edge_to_image bf16 bs=8 512^2, 1 GPU
+    python bench.py --gpus 8                           # spawns 8 ranks itself (torch.distributed.run, 127.0.0.1), weak scaling
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W         # what the driver runs for N > 1
+    python bench.py --model cyclegan --batch 4         # configs[2] per-GPU share (day_to_night bf16, 4 images / GPU)
+    python bench.py --stochastic --gamma 0.4 --batch 16          # configs[3] (sketch_to_image_stochastic, TwinConv, r-scaled LoRA)
+    python bench.py --size 1024 --dtype f16 --batch 8  # configs[4] per-GPU share
 
-A step = one pass of the hot path (VAE encode -> UNet @ t=999 -> DDPM step -> VAE decode with skips) over
-one batch of synthetic inputs already resident in HBM, replayed as a hipGraph; for N > 1 each rank runs its
-own batch shard (weak scaling, weights replicated, no data-path collective) and the finished images are
-gathered to rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path (VAE encode -> UNet @ t=999 -> DDPM step -> VAE decode with skips) over one batch
+of synthetic inputs already resident in HBM, replayed as a hipGraph; for N > 1 each rank runs its own batch shard
+(weak scaling, weights replicated, no data-path collective) and the finished images are gathered to rank 0 over RCCL
+inside the timed region.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries the roofline of the dominant
+kernel (HIP events on the launch stream), the bs=1 latency, the CPU oracle timed on image 0 of the SAME inputs, and
+the parity of the GPU output against that oracle image (``parity_max_abs`` / ``parity_psnr_db``).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
 import sys
 import time
@@ -28,14 +35,35 @@ PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI
 CPU_BASELINE_THREADS = 16
 PER_OP_PATH = None
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_conv3x3_halo.json")   # tools/pmc_traffic.py, PMC passes of THIS command
 
 
-def synth_inputs(B, size, cross_dim, lat, device, seed):
+def synth_inputs(kind, B, size, cross_dim, lat, seed):
+    """Seeded synthetic inputs on the CPU: 'canny' Bernoulli(0.08) edge maps in {0,1}, 'sketch' Bernoulli(0.05),
+    'photo' low-passed U(-1,1).  The caption embedding is drawn first so image i is the same for every batch size."""
     g = torch.Generator().manual_seed(seed)
-    x = (torch.rand(B, 1, size, size, generator=g) < 0.08).float().expand(B, 3, size, size).contiguous()
     cap = torch.randn(1, 77, cross_dim, generator=g)
+    if kind == "photo":
+        x = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+        x = torch.nn.functional.avg_pool2d(x, 9, 1, 4)
+        x = (x / x.abs().amax(dim=(1, 2, 3), keepdim=True)).contiguous()
+    else:
+        p = 0.08 if kind == "canny" else 0.05
+        x = (torch.rand(B, 1, size, size, generator=g) < p).float().expand(B, 3, size, size).contiguous()
     eps = torch.randn(B, lat, size // 8, size // 8, generator=g)
-    return x.to(device), cap.to(device), eps.to(device)
+    noise = torch.randn(B, lat, size // 8, size // 8, generator=g)
+    return x, cap, eps, noise
+
+
+def source_hash():
+    """sha256 over the kernel sources: a PMC traffic record is only replayed into the line for the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def kernel_roofline(plan, dtype_name, reps=2):
@@ -65,16 +93,17 @@ def kernel_roofline(plan, dtype_name, reps=2):
     n3 = sum(fam[k][2] for k in halo)
     achieved = f3 / (t3 * 1e-3) / 1e12
     peak = PEAK_TF[dtype_name]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_traffic_conv3x3_halo.json")     # written by tools/pmc_traffic.py from a PMC run of THIS command
-    if os.path.exists(tpath):
-        with open(tpath) as f:
+    traffic, traffic_src = None, None
+    if os.path.exists(TRAFFIC_JSON):
+        with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
-        if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name:
-            traffic = tj["hbm_bytes_per_launch"]
+        # only for the build and workload the counters were collected on; anything else reports null rather than a stale number
+        if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name and tj.get("size") == plan.H and tj.get("source_hash") == source_hash():
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("collected")
     roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel (halo-tiled 3x3 implicit-GEMM conv, incl. sub-pixel upsampler form)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, MI355X_MICROARCH.md HBM section)",
+            "traffic_source": traffic_src,
             "launches": n3, "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),
             "algorithmic_flops_per_launch": f3 / n3, "executed_mfma_flops_per_step": getattr(plan, "halo_flops_real", None)}
     breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None}
@@ -82,31 +111,48 @@ def kernel_roofline(plan, dtype_name, reps=2):
     return roof, breakdown, tot
 
 
-def cpu_baseline(weights, size, seed):
-    """The CPU oracle (pure-PyTorch fp32 restatement of the reference path) timed on this host's cores on a
-    bounded sample: one 512x512 image, one forward."""
-    from oracle.pipeline import ModelWeights, pix2pix_forward
-    mw = ModelWeights(weights.unet, weights.vae, weights.unet_arch, weights.vae_arch, weights.unet_scaling, weights.vae_scaling)
-    x, cap, eps = synth_inputs(1, size, weights.unet_arch.cross_attention_dim, weights.vae_arch.latent_channels, "cpu", seed)
+def cpu_baseline(a, weights, x, cap, eps, noise):
+    """The CPU oracle (pure-PyTorch fp32 restatement of the reference path, unmerged LoRA) timed on this host's cores on a
+    bounded sample: image 0 of the benchmarked batch, ONE forward, no warm-up.  Returns (record, oracle image)."""
+    from oracle.pipeline import ModelWeights, cyclegan_forward, pix2pix_forward
+    mw = ModelWeights(weights.unet, weights.vae, weights.unet_arch, weights.vae_arch, weights.unet_scaling, weights.vae_scaling,
+                      weights.vae_b2a)
     # oneDNN/OpenMP oversubscribe badly past a few dozen threads on these shapes (256 threads: 488 s for one
     # forward on the 256-core GPU box, 8 threads: 32 s): cap the pool and report the cap as `cores`
     torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
     t0 = time.time()
-    out = pix2pix_forward(mw, x, cap, eps)
+    if a.model == "cyclegan":
+        out = cyclegan_forward(mw, x[:1], cap, eps[:1], direction=a.direction)
+    elif a.stochastic:
+        out = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=a.gamma, noise_map=noise[:1])
+    else:
+        out = pix2pix_forward(mw, x[:1], cap, eps[:1])
     dt = time.time() - t0
     return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 image %dx%d, fp32, unmerged LoRA, one forward (%.1f s)" % (size, size, dt)}, out
+            "sample": "1 sample: image 0 of the batch (%dx%d), fp32, unmerged LoRA, one un-warmed forward (%.1f s)" % (a.size, a.size, dt)}, out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 8; 4 for --model cyclegan, 16 for --stochastic)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
     ap.add_argument("--arch", default="sd-turbo", choices=["sd-turbo", "tiny"])
+    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "cyclegan"])
+    ap.add_argument("--direction", default="a2b", choices=["a2b", "b2a"], help="CycleGAN direction (day_to_night = a2b)")
+    ap.add_argument("--stochastic", action="store_true", help="sketch_to_image_stochastic path: TwinConv, noise interpolation, r-scaled LoRA/skips")
+    ap.add_argument("--gamma", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -114,34 +160,55 @@ def main():
     a = ap.parse_args()
     global PER_OP_PATH
     PER_OP_PATH = a.per_op
+    if a.batch is None:
+        a.batch = 4 if a.model == "cyclegan" else (16 if a.stochastic else 8)
+    assert not (a.stochastic and a.model == "cyclegan")
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL; rank 0 prints the line)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     from img2img_turbo_amd import dp
     from img2img_turbo_amd.arch import SD_TURBO_UNET, SD_TURBO_VAE, TINY_UNET, TINY_VAE
+    from img2img_turbo_amd.cyclegan_turbo import CycleGAN_Turbo
     from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
-    from img2img_turbo_amd.synth import make_pix2pix_weights
+    from img2img_turbo_amd.synth import make_cyclegan_weights, make_pix2pix_weights
 
     rank, world, local = dp.init_from_env()
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N`, which spawns the ranks, or "
+                         "torch.distributed.run --nproc-per-node N)" % (a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     dtype = DTYPES[a.dtype]
     ua, va = (SD_TURBO_UNET, SD_TURBO_VAE) if a.arch == "sd-turbo" else (TINY_UNET, TINY_VAE)
-
-    weights = make_pix2pix_weights(ua, va, seed=1234 + 2)           # random init of the exact architecture
-    model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype)
     B = a.batch
-    x, cap, eps = synth_inputs(B, a.size, ua.cross_attention_dim, va.latent_channels, dev, 1234 + 2 + rank)
-    plan = model.get_plan(B, a.size, a.size)
-    plan.x_in.copy_(x)
-    plan.ctx.copy_(cap.to(dtype))
-    plan.eps.copy_(eps)
     total = B * world
+
+    # random init of the exact architecture (no checkpoints offline); every rank builds the same weights, its own images
+    if a.model == "cyclegan":
+        weights = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
+        model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype)
+        kind, cfg = "photo", 3
+    else:
+        weights = make_pix2pix_weights(ua, va, seed=1234 + (4 if a.stochastic else 2), sketch=a.stochastic)
+        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype)
+        kind, cfg = ("sketch", 4) if a.stochastic else ("canny", 2)
+    x, cap, eps, noise = synth_inputs(kind, B, a.size, ua.cross_attention_dim, va.latent_channels, 1234 + cfg + 1000 * rank)
+    if a.model == "cyclegan":
+        plan = model.get_plan(B, a.size, a.size, direction=a.direction)
+    else:
+        plan = model.get_plan(B, a.size, a.size, stochastic=a.stochastic, r=a.gamma)
+    model.stage(plan, x.to(dev), cap.to(dev), eps.to(dev), noise.to(dev) if a.stochastic else None)
+    gather = dp.OutputGather(plan.out, total) if (world > 1 and not a.no_gather) else None
 
     def step():
         plan.replay()
-        if world > 1 and not a.no_gather:
-            dp.gather_images(plan.out, total, dst=0)
+        if gather is not None:
+            gather()     # dist.gather (async_op=False): the launch stream waits for it, so the next replay cannot overwrite plan.out early
 
     for _ in range(a.warmup):
         step()
@@ -158,11 +225,14 @@ def main():
 
     if rank != 0:
         return
-    rec = {"metric": "512x512 images/sec (whole node), pix2pix-turbo edge_to_image forward", "value": round(value, 3),
+    name = {"pix2pix": "pix2pix-turbo sketch_to_image_stochastic gamma=%g" % a.gamma if a.stochastic else "pix2pix-turbo edge_to_image",
+            "cyclegan": "CycleGAN-Turbo day_to_night (%s)" % a.direction}[a.model]
+    headline = a.size == 512 and a.arch == "sd-turbo"
+    rec = {"metric": "512x512 images/sec (whole node), %s forward" % name, "value": round(value, 3),
            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": round(value / 9.09, 3) if (a.size == 512 and a.arch == "sd-turbo") else None,
-           "dtype": a.dtype, "data": "synthetic (random-init weights of the SD-Turbo architecture + LoRA r8/r4, Bernoulli edge maps)",
-           "config": {"workload": "pix2pix-turbo edge_to_image %s bs=%d/GPU %dx%d, deterministic path, hipGraph replay" % (a.dtype, B, a.size, a.size),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": round(value / 9.09, 3) if headline else None,
+           "dtype": a.dtype, "data": "synthetic (random-init weights of the SD-Turbo architecture + LoRA, seeded %s inputs)" % kind,
+           "config": {"workload": "%s %s bs=%d/GPU %dx%d, hipGraph replay" % (name, a.dtype, B, a.size, a.size),
                       "global_batch": total, "parallelism": "dp%d (batch shards, replicated weights, RCCL gather of outputs)" % world,
                       "arch": a.arch, "kernel_library": os.path.basename(model.lib.path)},
            "baseline_note": "vs_baseline = value / 9.09 img/s (0.11 s per 512x512 image on A100, reference README.md:17)"}
@@ -174,14 +244,29 @@ def main():
         rec["roofline"] = roof
         rec["kernel_breakdown_ms"] = breakdown
         rec["sum_kernel_ms"] = round(tot, 3)
+        # throughput through the public forward() (boundary copies + output clone included), same batch
+        fw = {"caption_enc" if a.model == "pix2pix" else "caption_emb": cap.to(dev), "eps": eps.to(dev)}
+        if a.model == "cyclegan":
+            fw["direction"] = a.direction
+        elif a.stochastic:
+            fw.update(deterministic=False, r=a.gamma, noise_map=noise.to(dev))
+        xd = x.to(dev)
+        out = model(xd, **fw)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            out = model(xd, **fw)
+        torch.cuda.synchronize()
+        rec["images_per_s_via_forward"] = round(5 * B / (time.perf_counter() - t), 2)
         if not a.no_latency:
-            p1 = model.get_plan(1, a.size, a.size)
-            p1.x_in.copy_(x[:1]); p1.ctx.copy_(cap.to(dtype)); p1.eps.copy_(eps[:1])
+            p1 = (model.get_plan(1, a.size, a.size, direction=a.direction) if a.model == "cyclegan" else
+                  model.get_plan(1, a.size, a.size, stochastic=a.stochastic, r=a.gamma))
+            model.stage(p1, xd[:1], cap.to(dev), eps[:1].to(dev), noise[:1].to(dev) if a.stochastic else None)
             for _ in range(3):
                 p1.replay()
             torch.cuda.synchronize()
             lat = []
-            for _ in range(20):
+            for _ in range(30):
                 t = time.perf_counter()
                 p1.replay()
                 torch.cuda.synchronize()
@@ -189,8 +274,14 @@ def main():
             rec["latency_bs1_ms_p50"] = round(statistics.median(lat), 3)
             rec["images_per_s_bs1"] = round(1e3 / statistics.median(lat), 2)
         if not a.no_cpu_baseline:
-            cb, _ = cpu_baseline(weights, a.size, 1234 + 2)
+            cb, ref = cpu_baseline(a, weights, x, cap, eps, noise)
             rec["cpu_baseline"] = cb
+            d = (out[:1].float().cpu() - ref).abs()
+            mse = float((d ** 2).mean())
+            rec["parity_max_abs"] = round(float(d.max()), 5)
+            rec["parity_mean_abs"] = round(float(d.mean()), 6)
+            rec["parity_psnr_db"] = round(10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20))).item(), 2)
+            rec["parity_note"] = "GPU %s image 0 of the benchmarked batch vs the CPU fp32 oracle on the same inputs, outputs in [-1,1]" % a.dtype
     print(json.dumps(rec), flush=True)
 
 

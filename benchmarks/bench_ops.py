@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on shape names")
     ap.add_argument("--lib", default=None, help="alternate build of the library (ablation experiments)")
     ap.add_argument("--splitk", default="0", help="comma list of split-K factors to try (LDS-DMA igemm)")
+    ap.add_argument("--trace", action="store_true", help="library built with -DI2I_TRACE=1: print the per-segment cycle split of the halo conv")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
@@ -76,6 +77,8 @@ def main():
         ss = torch.randn(B, cin, 2, device=dev) if gn else None
         for tile, sk in [(int(t), int(k)) for t in a.tiles.split(",") for k in a.splitk.split(",")]:
             ws = torch.empty(sk * B * ho * wo * cout, device=dev) if sk > 1 else None
+            if a.trace:
+                ws = torch.zeros(B * ho * wo * ((cout + 63) // 64) // 4, dtype=torch.int32, device=dev)   # >= workgroups * waves * 16
             prog = K.Program()
             for _ in range(a.iters + 1):
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
@@ -92,6 +95,14 @@ def main():
             rec = dict(name=name, tile=tile, splitk=sk, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
             res.append(rec)
             print("%-32s tile %d sk %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (name, tile, sk, t, tf, 100 * tf / peak), flush=True)
+            if a.trace:
+                tr = ws.view(-1, 16).cpu().double()
+                tr = tr[tr.sum(1) > 0]
+                tot = tr.sum(1).mean().item()
+                names = ["kgroup0", "vmcnt", "barrier", "issue", "kgroup1", "handover", "pro:setup+w0read", "epi:gnstats", "pro:setup+issue", "pro:vmcnt0", "pro:barrier", "pro:halo_store", "pro:barrier2",
+                         "epi:tail_vmcnt", "epi:bias+store", "-"]
+                print("   trace: %d waves, %.0f cycles/wave (%.2f GHz if the wave spans the launch): " % (len(tr), tot, tot / (t * 1e-3) / 1e9) +
+                      "  ".join("%s %.1f%%" % (n, 100 * tr[:, i].mean().item() / tot) for i, n in enumerate(names)), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)

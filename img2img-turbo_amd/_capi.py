@@ -14,6 +14,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libi2i_turbo.so")
 F32, BF16, F16, U8 = 0, 1, 2, 3
 OP_IGEMM, OP_GN_STATS, OP_LAYERNORM, OP_SOFTMAX = 1, 2, 3, 4
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY, OP_EMBED = 5, 6, 7, 8, 9, 10, 11
+OP_LORA_MERGE = 12
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -75,7 +76,7 @@ class NhwcToNchwParams(C.Structure):
 class PosteriorParams(C.Structure):
     _fields_ = [("moments", vp), ("eps", vp), ("noise", vp), ("u", vp),
                 ("n", i32), ("hw", i32), ("lat", i32), ("ldm", i32), ("ldu", i32), ("noise_n", i32),
-                ("sf", f32), ("r", f32), ("u_f32", vp), ("moments_f32", i32)]
+                ("sf", f32), ("r", f32), ("r_dev", vp), ("u_f32", vp), ("moments_f32", i32)]
 
 
 class DdpmParams(C.Structure):
@@ -84,11 +85,15 @@ class DdpmParams(C.Structure):
                 ("sqrt_abar", f32), ("sqrt_1m_abar", f32), ("sf", f32), ("u_f32", i32), ("e_f32", i32)]
 
 
+class LoraMergeParams(C.Structure):
+    _fields_ = [("dst", vp), ("w0", vp), ("a", vp), ("b", vp), ("N", i32), ("K", i32), ("rank", i32), ("use_gamma", i32), ("rg", vp)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmParams), ("gn_stats", GnStatsParams), ("gn_apply", GnApplyParams),
                 ("layernorm", LayerNormParams), ("softmax", SoftmaxParams), ("attention", AttentionParams),
                 ("to_nhwc", NchwToNhwcParams), ("to_nchw", NhwcToNchwParams), ("embed", EmbedParams),
-                ("posterior", PosteriorParams), ("ddpm", DdpmParams)]
+                ("posterior", PosteriorParams), ("ddpm", DdpmParams), ("lora_merge", LoraMergeParams)]
 
 
 class Op(C.Structure):
@@ -97,11 +102,12 @@ class Op(C.Structure):
 
 _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply", OP_LAYERNORM: "layernorm",
              OP_SOFTMAX: "softmax", OP_ATTENTION: "attention", OP_NCHW_TO_NHWC: "to_nhwc",
-             OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed"}
+             OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed",
+             OP_LORA_MERGE: "lora_merge"}
 
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
-           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_run", "i2i_run_timed",
+           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
 
 
@@ -154,7 +160,7 @@ class Library:
         L.i2i_last_error.restype = C.c_char_p
         L.i2i_sizeof_op.restype = C.c_size_t
         for name in ("i2i_igemm", "i2i_gn_stats", "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention",
-                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed"):
+                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge"):
             getattr(L, name).argtypes = [vp, C.c_int, vp]
             getattr(L, name).restype = C.c_int
         L.i2i_igemm_gn_parts.argtypes = [vp, C.c_int, C.c_int]
@@ -164,7 +170,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 2:
+        if L.i2i_abi_version() != 3:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

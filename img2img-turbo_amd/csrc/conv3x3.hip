@@ -67,6 +67,21 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lq = lane >> 4;
     const int kc = tid & 7;
+    // Measurement hook (csrc/build.py --tag trace --defs=-DI2I_TRACE=1; never in the product build): every wave sums the
+    // shader cycles (s_memtime) it spends in each segment of the step pipeline and writes the eight totals to p.ws
+    // [workgroup][wave][8] at the end (benchmarks/bench_ops.py --trace prints the averages).  The s_memtime reads drain
+    // lgkmcnt, so the traced kernel is ~10 % slower than the product one; the split between segments is what it is for.
+#ifdef I2I_TRACE
+    unsigned tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tr_t = (unsigned)__builtin_amdgcn_s_memtime();
+#define I2I_TR(k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; } while (0)
+    // ablation switches of the trace build (p.splitk is otherwise unused by this kernel; results are WRONG with any bit set):
+    // 1 no output stores, 2 no bias loads, 4 no weight DMA inside the step loop, 8 no MFMAs, 16 no halo loads inside the step loop
+#define I2I_ABL(bit) ((p.splitk & (bit)) != 0)
+#else
+#define I2I_TR(k) do { } while (0)
+#define I2I_ABL(bit) false
+#endif
 
     // ---- XCD-aware tile id: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles so
     // neighbouring tiles (shared halo rows, same weights) meet in the same L2 (bijective for any grid).
@@ -229,7 +244,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     if (has_gn) ss_dma(0, 0);
 #pragma unroll
     for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
+    I2I_TR(8);
     wait_vmcnt<0>();
+    I2I_TR(9);
     // I2I_GLDS_ASM build: retire these loads in hipcc's own bookkeeping on EVERY path, here: their consumers below sit in
     // per-lane conditionals, and a load the compiler still considers pending on the skipped path gets a vmcnt wait at the
     // first reuse of its register -- inside the slab loop, draining the (then invisible) DMA ring there
@@ -238,8 +255,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
 #endif
     lds_barrier();
+    I2I_TR(10);
     halo_store_all();
+    I2I_TR(11);
     lds_barrier();
+    I2I_TR(12);
 
     // ---- per-lane LDS read offsets, all precomputed so that every fragment read is "register + immediate":
     // pixel fragment row = W + c + lr with W = wm*FM*18 (wave) and c = (i+dy)*18 + dx (compile time).  The
@@ -306,7 +326,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             }
         }
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], xq[g % 4], acc[i][j]);
+        for (int j = 0; j < FN; ++j) if (!I2I_ABL(8)) acc[i][j] = mma_chunk(kg == 0 ? w0[j] : w1[j], xq[g % 4], acc[i][j]);
         if constexpr (nw + (xpre ? 1 : 0) > 0) __builtin_amdgcn_sched_group_barrier(0x100, nw + (xpre ? 1 : 0), 0);
         __builtin_amdgcn_sched_group_barrier(0x008, FN * MPC, 0);
     };
@@ -331,6 +351,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         }
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, gc, more); });
         __builtin_amdgcn_sched_barrier(0);
+        I2I_TR(0);
         // -- P_s: publish B[s+1].  Outstanding VMEM ops allowed = the window issued after P_{s-1}: the halo loads of
         //    tap-1 (always issued) and, if it exists, the DMA batch of B[s+2].  At tap 0 the previous window is
         //    tap 8 of the previous slab, whose halo loads the hand-over already waited for.
@@ -341,7 +362,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         } else {
             wait_vmcnt<0>();                              // 2-deep ring: B[s+1] is the most recent batch
         }
+        I2I_TR(1);
         lds_barrier();
+        I2I_TR(2);
         if constexpr (DBH) {
             // -- window after P_s (every P waited vmcnt(0): the loads of the previous window have landed).
             //    Chunks j = t, t+L, t+2L are loaded in tap t's window (t < L = NTAPS-2), transformed and stored
@@ -376,17 +399,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         //    just released.  Halo first: the hand-over then waits with vmcnt(DMA_OPS) and leaves the DMA in flight.
         {
             const int hs = next_slab ? slab + 1 : slab;
+            if (!I2I_ABL(16)) {
             if constexpr (tap < HPT) halo_load(hs, tap, true);
             if constexpr (tap + NTAPS < HPT) halo_load(hs, tap + NTAPS, true);
             if constexpr (tap + 2 * NTAPS < HPT) halo_load(hs, tap + 2 * NTAPS, true);
+            }
             static_assert(DBH || 3 * NTAPS >= HPT, "halo loads do not fit the taps of a slab");
         }
+        if (!I2I_ABL(4)) {
         if (tap + RING < NTAPS) b_dma(slab, tap + RING, tap % RING);
         else if (next_slab) b_dma(slab + 1, tap + RING - NTAPS, tap % RING);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        I2I_TR(3);
         static_for<FM>([&](auto gc) __attribute__((always_inline)) { row_group(tapc, ic<decltype(gc)::value + FM>{}, more); });
         __builtin_amdgcn_sched_barrier(0);
+        I2I_TR(4);
         if constexpr (DBH) {
             w_off ^= BN * 128;                            // next step multiplies the other weight buffer
             bcur ^= 1;
@@ -403,12 +432,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             lds_barrier();
             halo_store_all();
             lds_barrier();
+            I2I_TR(5);
         }
     };
 
     // first weights of the first step (every later step finds w0 preloaded by its predecessor)
 #pragma unroll
     for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);     // buffer 0 in both layouts
+    I2I_TR(6);
     for (int slab = 0; slab < nslab; ++slab) {
         const bool next_slab = slab + 1 < nslab;
         static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, tc); });
@@ -418,6 +449,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     wait_vmcnt<0>();
 #pragma unroll
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+    I2I_TR(13);
 
     // ---- epilogue: alpha, bias, residual, store, GroupNorm partial sums of what was stored.
     // Lane (lr, lq) holds pixel (oy, tx0 + lr).  16-bit outputs with an even fragment count take the wide path:
@@ -458,7 +490,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                 gquad[2 * jp] = cw >> 2; gquad[2 * jp + 1] = (cw >> 2) + 1;
                 float bv[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N) ? p.bias[n + r] : 0.f;
+                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N && !I2I_ABL(2)) ? p.bias[n + r] : 0.f;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     float v[8];
@@ -475,7 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                     chunk_t o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
-                    *(chunk_t*)((T*)p.c + m * p.ldc + n) = o;
+                    if (!I2I_ABL(1)) *(chunk_t*)((T*)p.c + m * p.ldc + n) = o;
                     if (do_stats) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
@@ -537,6 +569,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             }
         }
     }
+    I2I_TR(14);
     // ---- GroupNorm partial sums: lane -> 16 pixels (shuffles) -> wave (LDS) -> workgroup -> one slot per group.
     // Fixed reduction order: deterministic.  Only full 4-channel vectors were accumulated (host checks N % 4 == 0,
     // dtype output, channels-per-group a multiple of 4 that divides the wave's channel span).
@@ -575,6 +608,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             out[1] = Q;
         }
     }
+#ifdef I2I_TRACE
+    I2I_TR(7);
+    if (p.ws && lane == 0) {
+        unsigned* o = (unsigned*)p.ws + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = tr_acc[k];
+    }
+#endif
+#undef I2I_TR
+#undef I2I_ABL
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false, bool DBH = false>

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const i2i_embed_params p) {
 template <typename T>
 __global__ __launch_bounds__(256) void posterior_kernel(const i2i_posterior_params p) {
     const int64_t total = (int64_t)p.n * p.hw;
+    const float r = p.r_dev ? p.r_dev[0] : p.r;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t img = i / p.hw, px = i - img * p.hw;
         const T* m = (const T*)p.moments + i * p.ldm;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const i2i_posterior_para
                 v = (mean + __expf(0.5f * logvar) * e) * p.sf;
                 if (p.noise) {
                     const int64_t nimg = (p.noise_n == 1) ? 0 : img;
-                    v = v * p.r + p.noise[(nimg * p.lat + c) * p.hw + px] * (1.f - p.r);
+                    v = v * r + p.noise[(nimg * p.lat + c) * p.hw + px] * (1.f - r);
                 }
             }
             u[c] = from_f32<T>(v);

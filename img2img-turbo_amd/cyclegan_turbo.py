@@ -9,7 +9,7 @@ from typing import Optional
 
 import torch
 
-from .pix2pix_turbo import TurboGeneratorBase
+from .pix2pix_turbo import TurboGeneratorBase, _NetHandle
 from .weights import GeneratorWeights, from_cyclegan_checkpoint, load_checkpoint_file, load_sd_turbo_base
 
 PRETRAINED = {  # src/cyclegan_turbo.py:126-149: name -> (checkpoint file, caption, direction)
@@ -20,22 +20,16 @@ PRETRAINED = {  # src/cyclegan_turbo.py:126-149: name -> (checkpoint file, capti
 }
 
 
-class _XformersShim:
-    """``model.unet.enable_xformers_memory_efficient_attention()`` (src/inference_unpaired.py:36) is accepted:
-    the fused flash-style attention kernel is always on."""
-
-    def enable_xformers_memory_efficient_attention(self):
-        return None
-
-
 class CycleGAN_Turbo(TurboGeneratorBase):
     def __init__(self, pretrained_name=None, pretrained_path=None, ckpt_folder="checkpoints", lora_rank_unet=8, lora_rank_vae=4,
                  *, weights: Optional[GeneratorWeights] = None, base_dir=None, caption=None, direction=None, **kw):
         self.caption, self.direction = caption, direction
         if weights is None:
             import os
+            base_dir = base_dir or os.environ.get("I2I_SD_TURBO_DIR")
             if base_dir is None:
-                raise ValueError("give weights=GeneratorWeights(...) or base_dir=<local sd-turbo snapshot> (no network here)")
+                raise ValueError("give weights=GeneratorWeights(...), base_dir=<local sd-turbo snapshot> or set I2I_SD_TURBO_DIR "
+                                 "(no network here)")
             if pretrained_name in PRETRAINED:
                 fn, cap, dr = PRETRAINED[pretrained_name]
                 pretrained_path = os.path.join(ckpt_folder, fn)
@@ -46,7 +40,10 @@ class CycleGAN_Turbo(TurboGeneratorBase):
             weights = from_cyclegan_checkpoint(unet, load_checkpoint_file(pretrained_path))
         super().__init__(weights, **kw)
         self.caption, self.direction = caption, direction
-        self.unet = _XformersShim()
+        # the wrappers the reference builds at src/cyclegan_turbo.py:115-116 (each holds both VAEs, picks one per direction)
+        self.vae_enc = _NetHandle("vae_enc", weights.vae, weights.vae_b2a if weights.vae_b2a is not None else weights.vae)
+        self.vae_dec = _NetHandle("vae_dec", weights.vae, weights.vae_b2a if weights.vae_b2a is not None else weights.vae)
+        self.vae_enc._model = self.vae_dec._model = self.unet._model = self
 
     @torch.no_grad()
     def forward_u8(self, images_u8, *args, **kw):
@@ -54,6 +51,23 @@ class CycleGAN_Turbo(TurboGeneratorBase):
         ``ToPILImage()(out*0.5+0.5)`` (:53) run inside the boundary kernels."""
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
         return self.forward(images_u8, *args, _u8_io=(2.0, -1.0), **kw)
+
+    @staticmethod
+    @torch.no_grad()
+    def forward_with_networks(x, direction, vae_enc, unet, vae_dec, sched, timesteps, text_emb, *, eps=None):
+        """Static generator entry of the reference (src/cyclegan_turbo.py:199-207), called as
+        ``CycleGAN_Turbo.forward_with_networks(x, "a2b", model.vae_enc, model.unet, model.vae_dec, model.sched,
+        model.timesteps, text_emb)`` (src/train_cyclegan_turbo.py:181).  The three network arguments must be the handles of
+        ONE model of this package (they name its planned program: vae_enc(x, direction) -> unet -> per-sample sched.step ->
+        vae_dec(x, direction)); ``sched`` / ``timesteps`` are the fixed one-step schedule and are checked, not used."""
+        model = getattr(unet, "_model", None)
+        if model is None or getattr(vae_enc, "_model", None) is not model or getattr(vae_dec, "_model", None) is not model:
+            raise ValueError("forward_with_networks: pass model.vae_enc, model.unet, model.vae_dec of one CycleGAN_Turbo")
+        assert direction in ("a2b", "b2a")
+        ts = [int(t) for t in (timesteps.tolist() if hasattr(timesteps, "tolist") else list(timesteps))]
+        if any(t != model.weights.unet_arch.timestep for t in ts):
+            raise ValueError("the planned forward is specialised for the reference's fixed timestep %d" % model.weights.unet_arch.timestep)
+        return model.forward(x, direction=direction, caption_emb=text_emb, eps=eps)
 
     @torch.no_grad()
     def forward(self, x_t, direction=None, caption=None, caption_emb=None, *, eps=None, _u8_io=None):

@@ -37,24 +37,50 @@ def shard(t, rank, world):
     return t[lo:hi]
 
 
-def gather_images(local, total, dst=0):
-    """Gather per-rank output slices [b_r, 3, H, W] into [total, 3, H, W] on ``dst`` (None elsewhere).
+class OutputGather:
+    """Gather of the finished images to ``dst`` into buffers allocated ONCE (the timed loop of bench.py / a serving loop
+    calls it every step): ``local`` is the plan's static output buffer [b_r, ...]; rank ``dst`` owns one
+    [world, max_shard, ...] slab whose per-rank views are the gather list.  Ragged shards are padded to the largest.
 
-    Equal shards use one ``dist.gather``; ragged shards pad to the largest shard."""
+    ``dist.gather`` with async_op=False makes the CURRENT stream wait for the collective, so a following hipGraph replay
+    on that stream cannot overwrite ``local`` while RCCL still reads it."""
+
+    def __init__(self, local, total, dst=0):
+        self.local, self.total, self.dst = local, total, dst
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.sizes = [shard_bounds(total, r, self.world)[1] - shard_bounds(total, r, self.world)[0] for r in range(self.world)]
+        mx = max(self.sizes)
+        self.send = local
+        if local.shape[0] != mx:
+            self.send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self.slab = self.views = None
+        if self.rank == dst:
+            self.slab = torch.empty((self.world, mx) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            self.views = [self.slab[r] for r in range(self.world)]
+
+    def __call__(self):
+        """-> on ``dst``: the slab [world, max_shard, ...] (rank r's images are slab[r, :sizes[r]]); None elsewhere."""
+        if self.send is not self.local:
+            self.send[: self.local.shape[0]].copy_(self.local)
+        dist.gather(self.send, self.views, dst=self.dst)
+        return self.slab
+
+    def images(self):
+        """[total, ...] on ``dst`` in global batch order (a copy only when shards are ragged)."""
+        if self.rank != self.dst:
+            return None
+        if len(set(self.sizes)) == 1:
+            return self.slab.reshape((self.total,) + tuple(self.slab.shape[2:]))
+        return torch.cat([self.slab[r, :s] for r, s in enumerate(self.sizes)], dim=0)
+
+
+def gather_images(local, total, dst=0):
+    """One-shot form of OutputGather: per-rank slices [b_r, 3, H, W] -> [total, 3, H, W] on ``dst`` (None elsewhere)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
-    mx = max(sizes)
-    buf = local
-    if local.shape[0] != mx:
-        buf = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        buf[: local.shape[0]] = local
-    outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf.contiguous(), outs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    g = OutputGather(local.contiguous(), total, dst)
+    g()
+    return g.images()
 
 
 def max_over_ranks(value, device):

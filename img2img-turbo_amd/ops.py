@@ -145,8 +145,9 @@ def nhwc_to_nchw(x, y, *, n, c, h, w, ldx, clamp=0, mul=0.0, add=0.0):
     return K.OP_NHWC_TO_NCHW, p
 
 
-def posterior(moments, eps, u, *, n, hw, lat, ldm, ldu, sf, r=1.0, noise=None, noise_n=0, u_f32=None, moments_f32=0):
+def posterior(moments, eps, u, *, n, hw, lat, ldm, ldu, sf, r=1.0, noise=None, noise_n=0, u_f32=None, moments_f32=0, r_dev=None):
     p = K.PosteriorParams()
+    p.r_dev = ptr(r_dev)
     p.moments, p.eps, p.noise, p.u = ptr(moments), ptr(eps), ptr(noise), ptr(u)
     p.n, p.hw, p.lat, p.ldm, p.ldu, p.noise_n, p.sf, p.r = n, hw, lat, ldm, ldu, noise_n, sf, r
     p.u_f32, p.moments_f32 = ptr(u_f32), moments_f32

@@ -12,6 +12,7 @@ reference signature and semantics (:186-219).  Differences, all explicit:
     ``tokenizer`` pair (CLIP weights are not available offline).
 All arithmetic runs in the HIP kernels behind include/i2i_turbo.h; there is no torch/diffusers fallback.
 """
+import collections
 from typing import Optional
 
 import torch
@@ -23,14 +24,53 @@ from .packer import Packer
 from .weights import GeneratorWeights, from_pix2pix_checkpoint, load_checkpoint_file, load_sd_turbo_base
 
 
+class _NetHandle:
+    """What callers reach through ``model.unet`` / ``model.vae`` / ``model.vae_enc`` / ``model.vae_dec``
+    (src/pix2pix_turbo.py:161, src/cyclegan_turbo.py:186-190): the canonical state dict of that network plus the no-op
+    switches the reference scripts call on it (``enable_xformers_memory_efficient_attention`` src/inference_unpaired.py:36,
+    ``eval`` / ``requires_grad_`` / ``to``).  The arithmetic itself lives in the planned program, not in these objects."""
+
+    def __init__(self, name, sd, sd_b2a=None):
+        self.name, self._sd, self._sd_b2a = name, sd, sd_b2a
+
+    def state_dict(self):
+        if self._sd_b2a is None:
+            return dict(self._sd)
+        out = {"vae." + k: v for k, v in self._sd.items()}         # VAE_encode / VAE_decode wrap both VAEs (:15-45)
+        out.update({"vae_b2a." + k: v for k, v in self._sd_b2a.items()})
+        return out
+
+    def enable_xformers_memory_efficient_attention(self):
+        return None            # the fused flash-style attention kernel is always on
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training (autograd through the generator) is out of scope of the MI355X forward path")
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+
 class TurboGeneratorBase(torch.nn.Module):
-    """Shared plumbing: plan cache, packer cache, boundary staging, text conditioning."""
+    """Shared plumbing: plan cache (LRU, graphs released on eviction), packers (one per network and dtype; the LoRA scale r is
+    re-merged on the device), boundary staging, text conditioning."""
+
+    MAX_PLANS = 8          # distinct (batch, size, mode) programs kept alive; each owns an activation pool + a hipGraph
 
     def __init__(self, weights: GeneratorWeights, device="cuda", dtype=torch.float32, lib=None,
                  tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None):
         super().__init__()
         self.weights = weights
         self.device_ = torch.device(device)
+        if self.device_.type == "cuda" and self.device_.index is None:
+            self.device_ = torch.device("cuda", torch.cuda.current_device())
         self.dtype_ = dtype
         self.lib = lib or _capi.default_library()     # raises if the HIP build is missing: no fallback
         if self.lib.backend == "gfx950" and self.device_.type != "cuda":
@@ -41,9 +81,11 @@ class TurboGeneratorBase(torch.nn.Module):
         self.use_graph = use_graph and self.lib.backend == "gfx950"
         self.fuse_gn, self.flash = fuse_gn, flash
         self.plan_options = dict(plan_options or {})   # extra ForwardPlan switches (tests / ablations): halo_min_tiles, subpix, ...
-        self._plans = {}
+        self._plans = collections.OrderedDict()
         self._packers = {}
         self._caption_cache = {}
+        self._r = 1.0
+        self.unet = _NetHandle("unet", weights.unet)
 
     # ---- reference-compatible no-ops / switches ----
     def set_eval(self):
@@ -64,32 +106,63 @@ class TurboGeneratorBase(torch.nn.Module):
     def to_dtype(self, dtype):
         if dtype != self.dtype_:
             self.dtype_ = dtype
-            self._plans.clear()
+            self.release_plans()
             self._packers.clear()
         return self
 
+    def release_plans(self):
+        for plan in self._plans.values():
+            plan.release()
+        self._plans.clear()
+
     # ---- plumbing ----
-    def _get_packers(self, r, direction):
-        key = (self.dtype_, round(float(r), 6), direction)
+    def _on_device(self):
+        import contextlib
+        return torch.cuda.device(self.device_) if self.device_.type == "cuda" else contextlib.nullcontext()
+
+    def _packer(self, which):
+        """One packer per network ('unet', 'vae', 'vae_b2a') and dtype: base weights are packed and uploaded once, the LoRA
+        merge at the current r runs on the device (Packer.set_scale)."""
+        key = (self.dtype_, which)
         if key not in self._packers:
             w = self.weights
-            vae_sd = w.vae if (direction == "a2b" or w.vae_b2a is None) else w.vae_b2a
-            unet_key = (self.dtype_, round(float(r), 6), "unet")
-            if unet_key not in self._packers:
-                self._packers[unet_key] = Packer(w.unet, w.unet_scaling, self.dtype_, self.device_, r)
-            self._packers[key] = (self._packers[unet_key], Packer(vae_sd, w.vae_scaling, self.dtype_, self.device_, r))
+            sd, sc = {"unet": (w.unet, w.unet_scaling), "vae": (w.vae, w.vae_scaling), "vae_b2a": (w.vae_b2a, w.vae_scaling)}[which]
+            with self._on_device():
+                self._packers[key] = Packer(sd, sc, self.dtype_, self.device_, self.lib, self._r, self._r)
         return self._packers[key]
 
+    def _get_packers(self, direction):
+        vae = "vae" if (direction == "a2b" or self.weights.vae_b2a is None) else "vae_b2a"
+        return self._packer("unet"), self._packer(vae)
+
+    def set_lora_scale(self, r: float):
+        """The reference's per-call ``unet.set_adapters(["default"], weights=[r])`` +
+        ``set_weights_and_activate_adapters(vae, ["vae_skip"], [r])`` + ``decoder.gamma = r`` + ``conv_in.r = r``
+        (src/pix2pix_turbo.py:206-217) as ONE device-side re-merge of the packed weights (csrc/lora_merge.hip): no re-pack,
+        no re-upload, plans and captured graphs stay valid.  Asynchronous on the current stream."""
+        r = float(r)
+        if r != self._r:
+            self._r = r
+            with self._on_device():
+                for pk in self._packers.values():
+                    pk.set_scale(r, r)
+
     def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1, u8_io=None) -> ForwardPlan:
-        r_eff = float(r) if stochastic else 1.0
-        key = (B, H, W, self.dtype_, stochastic, round(r_eff, 6), direction, ctx_batch, u8_io)
-        if key not in self._plans:
+        self.set_lora_scale(float(r) if stochastic else 1.0)
+        key = (B, H, W, self.dtype_, stochastic, direction, ctx_batch, u8_io)
+        if key in self._plans:
+            self._plans.move_to_end(key)
+        else:
             opts = dict(self.plan_options)
             if u8_io is not None:
                 opts["u8_io"] = u8_io
-            self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
-                                           r=r_eff, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
-                                           flash=self.flash, packers=self._get_packers(r_eff, direction), **opts)
+            with self._on_device():
+                self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
+                                               r=self._r, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
+                                               flash=self.flash, packers=self._get_packers(direction), **opts)
+            while len(self._plans) > self.MAX_PLANS:      # LRU: the evicted plan's graph and activation pool are released
+                _, old = self._plans.popitem(last=False)
+                old.release()
         return self._plans[key]
 
     def encode_prompt(self, prompt=None, prompt_tokens=None):
@@ -108,17 +181,22 @@ class TurboGeneratorBase(torch.nn.Module):
         ids = prompt_tokens.reshape(-1, prompt_tokens.shape[-1])   # [B,1,77] from the training dataset (A.5)
         return self.text_encoder(ids.to(self.device_))[0].detach()
 
-    def _execute(self, plan: ForwardPlan, x, caption_enc, eps, noise_map=None):
+    def stage(self, plan: ForwardPlan, x, caption_enc, eps, noise_map=None):
+        """Copy one batch into the plan's static boundary buffers (device-to-device when the inputs are already resident)."""
         plan.x_in.copy_(x)
         plan.ctx.copy_(caption_enc.reshape(plan.ctx.shape))
         plan.eps.copy_(eps)
         if noise_map is not None:
             plan.noise.copy_(noise_map.expand_as(plan.noise))
-        if self.use_graph:
-            plan.replay()
-        else:
-            plan.run()
-        return plan.out.clone()
+
+    def _execute(self, plan: ForwardPlan, x, caption_enc, eps, noise_map=None):
+        with self._on_device():
+            self.stage(plan, x, caption_enc, eps, noise_map)
+            if self.use_graph:
+                plan.replay()
+            else:
+                plan.run()
+            return plan.out.clone()
 
 
 class Pix2Pix_Turbo(TurboGeneratorBase):
@@ -127,8 +205,10 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
         if weights is None:
             # local-file counterpart of src/pix2pix_turbo.py:47-130: base SD-Turbo snapshot + LoRA .pkl
             import os
-            if base_dir is None:
-                raise ValueError("give weights=GeneratorWeights(...) or base_dir=<local sd-turbo snapshot> (no network here)")
+            base_dir = base_dir or os.environ.get("I2I_SD_TURBO_DIR")      # so Pix2Pix_Turbo(pretrained_name=...) works as written
+            if base_dir is None:                                            # in src/inference_paired.py:31
+                raise ValueError("give weights=GeneratorWeights(...), base_dir=<local sd-turbo snapshot> or set I2I_SD_TURBO_DIR "
+                                 "(the reference downloads stabilityai/sd-turbo from the hub; there is no network here)")
             names = {"edge_to_image": "edge_to_image_loras.pkl", "sketch_to_image_stochastic": "sketch_to_image_stochastic_lora.pkl"}
             if pretrained_name in names:
                 pretrained_path = os.path.join(ckpt_folder, names[pretrained_name])
@@ -138,6 +218,11 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
             weights = from_pix2pix_checkpoint(unet, vae, load_checkpoint_file(pretrained_path))
         super().__init__(weights, **kw)
         self.lora_rank_unet, self.lora_rank_vae = lora_rank_unet, lora_rank_vae
+        self.vae = _NetHandle("vae", weights.vae)
+        self.target_modules_unet = weights.meta.get("unet_lora_target_modules")
+        self.target_modules_vae = weights.meta.get("vae_lora_target_modules")
+        if weights.meta.get("rank_unet"):
+            self.lora_rank_unet, self.lora_rank_vae = weights.meta["rank_unet"], weights.meta["rank_vae"]
 
     @torch.no_grad()
     def forward_u8(self, images_u8, *args, **kw):
@@ -176,10 +261,11 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
         return out.to(c_t.dtype) if c_t.dtype in (torch.float16, torch.bfloat16, torch.float32) else out
 
     def save_model(self, outf):
-        """Same dict layout as the reference (src/pix2pix_turbo.py:221-229)."""
-        from .weights import GeneratorWeights  # noqa: F401
-        sd = {"unet_lora_target_modules": getattr(self, "target_modules_unet", None),
-              "vae_lora_target_modules": getattr(self, "target_modules_vae", None),
+        """Same dict layout as the reference (src/pix2pix_turbo.py:221-229): keys as ``unet.state_dict()`` /
+        ``vae.state_dict()`` name them after adapter injection (``X.base_layer.weight``, ``X.lora_A.<adapter>.weight``),
+        filtered with the reference's substring tests, so the file loads back through from_pix2pix_checkpoint (and into the
+        reference itself)."""
+        sd = {"unet_lora_target_modules": self.target_modules_unet, "vae_lora_target_modules": self.target_modules_vae,
               "rank_unet": self.lora_rank_unet, "rank_vae": self.lora_rank_vae,
               "state_dict_unet": {k: v for k, v in self.weights.unet.items() if "lora" in k or "conv_in" in k},
               "state_dict_vae": {k: v for k, v in self.weights.vae.items() if "lora" in k or "skip" in k}}

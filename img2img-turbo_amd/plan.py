@@ -69,7 +69,8 @@ def one_step_scheduler_constants(t=999, n=1000, beta_start=0.00085, beta_end=0.0
 
 
 class ForwardPlan:
-    """One planned forward for fixed (B, H, W, dtype, r, direction)."""
+    """One planned forward for fixed (B, H, W, dtype, stochastic?, direction).  The LoRA scale / skip gamma ``r`` is NOT part
+    of the plan: it lives in the packers' device scalars (Packer.set_scale), so one plan (and its hipGraph) serves every r."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
                  ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True):
@@ -89,8 +90,8 @@ class ForwardPlan:
         self.ua, self.va = weights.unet_arch, weights.vae_arch
         vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
         if packers is None:
-            packers = (Packer(weights.unet, weights.unet_scaling, dtype, device, self.r),
-                       Packer(vae_sd, weights.vae_scaling, dtype, device, self.r))
+            packers = (Packer(weights.unet, weights.unet_scaling, dtype, device, lib, self.r, self.r),
+                       Packer(vae_sd, weights.vae_scaling, dtype, device, lib, self.r, self.r))
         self.pu, self.pv = packers
         self.pool = Pool(device)
         self.pool.no_reuse = debug
@@ -543,7 +544,8 @@ class ForwardPlan:
         for i, c in enumerate(rboc):
             sk = skips[::-1][i]
             # sample = sample + skip_conv_i(skip * gamma)   (src/model.py:41-43), in place
-            self.conv(pk.conv(f"decoder.skip_conv_{i + 1}"), sk, ks=1, alpha=self.r, res=h, out=h, label=f"decoder.skip_conv_{i + 1}")
+            # (gamma is folded into the skip-conv weights by the device-side merge: Packer.conv(gamma=True))
+            self.conv(pk.conv(f"decoder.skip_conv_{i + 1}", gamma=True), sk, ks=1, res=h, out=h, label=f"decoder.skip_conv_{i + 1}")
             self.free(sk)
             for j in range(a.layers_per_block + 1):
                 h2 = self.resnet(pk, f"decoder.up_blocks.{i}.resnets.{j}", h, c, g, eps)
@@ -573,6 +575,7 @@ class ForwardPlan:
         self.u32 = torch.zeros(B * h8 * w8 * lat, dtype=torch.float32, device=self.device)
         sf = self.va.scaling_factor
         self._add(O.posterior(moments.t, self.eps, u.t, n=B, hw=h8 * w8, lat=lat, ldm=moments.c, ldu=8, sf=sf, r=self.r,
+                              r_dev=self.pv.rg if self.stochastic else None,
                               noise=self.noise, noise_n=B, u_f32=self.u32, moments_f32=1), "posterior_sample")
         self.free(moments)
         e = self._unet(u)
@@ -590,19 +593,38 @@ class ForwardPlan:
             t.zero_()
 
     # ------------------------------------------------------------------ execution
+    def _on_device(self):
+        """Make the plan's device current for the launches (kernels run where their pointers live even when the caller's
+        current device is another GPU); a no-op context for the CPU emulator."""
+        import contextlib
+        return torch.cuda.device(self.device) if torch.device(self.device).type == "cuda" else contextlib.nullcontext()
+
     def stream(self):
-        return torch.cuda.current_stream().cuda_stream if torch.device(self.device).type == "cuda" else 0
+        return torch.cuda.current_stream(self.device).cuda_stream if torch.device(self.device).type == "cuda" else 0
 
     def run(self):
-        self.lib.run(self.prog, self.stream())
+        with self._on_device():
+            self.lib.run(self.prog, self.stream())
 
     def capture(self):
         if self.graph is None:
-            self.graph = self.lib.graph_create(self.prog)
+            with self._on_device():
+                self.graph = self.lib.graph_create(self.prog)
         return self.graph
 
     def replay(self):
-        self.lib.graph_launch(self.capture(), self.stream())
+        with self._on_device():
+            self.lib.graph_launch(self.capture(), self.stream())
 
     def run_timed(self):
-        return self.lib.run_timed(self.prog, self.stream())
+        with self._on_device():
+            return self.lib.run_timed(self.prog, self.stream())
+
+    def release(self):
+        """Destroy the captured hipGraph and drop the activation pool (plan-cache eviction)."""
+        if self.graph is not None:
+            self.lib.graph_destroy(self.graph)
+            self.graph = None
+        self.pool.all.clear()
+        self.pool.free_lists.clear()
+        self._keep.clear()

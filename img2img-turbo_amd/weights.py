@@ -29,6 +29,7 @@ class GeneratorWeights:
     unet_scaling: Dict[str, float] = field(default_factory=dict)
     vae_scaling: Dict[str, float] = field(default_factory=dict)
     vae_b2a: Optional[Dict[str, torch.Tensor]] = None
+    meta: Dict[str, object] = field(default_factory=dict)     # checkpoint fields carried through for save_model (ranks, target module lists)
 
     @property
     def is_twin_conv(self):
@@ -63,9 +64,10 @@ def from_pix2pix_checkpoint(base_unet, base_vae, ckpt, unet_arch=SD_TURBO_UNET, 
         unet.pop("conv_in.bias", None)
     _wrap_adapted(unet)
     _wrap_adapted(vae)
+    meta = {k: ckpt.get(k) for k in ("unet_lora_target_modules", "vae_lora_target_modules", "rank_unet", "rank_vae")}
     return GeneratorWeights(unet, vae, unet_arch, vae_arch,
                             unet_scaling={"default": 8.0 / ckpt["rank_unet"]},
-                            vae_scaling={"vae_skip": 8.0 / ckpt["rank_vae"]})
+                            vae_scaling={"vae_skip": 8.0 / ckpt["rank_vae"]}, meta=meta)
 
 
 def from_cyclegan_checkpoint(base_unet, ckpt, unet_arch=SD_TURBO_UNET, vae_arch=SD_TURBO_VAE) -> GeneratorWeights:
@@ -93,7 +95,9 @@ def from_cyclegan_checkpoint(base_unet, ckpt, unet_arch=SD_TURBO_UNET, vae_arch=
 
 
 def load_sd_turbo_base(root):
-    """Read ``<root>/unet/diffusion_pytorch_model.safetensors`` and ``<root>/vae/...`` (local HF snapshot)."""
+    """Read ``<root>/unet/diffusion_pytorch_model.safetensors`` and ``<root>/vae/...`` (a local snapshot of
+    stabilityai/sd-turbo as ``from_pretrained(..., subfolder="unet"|"vae")`` lays it out, src/pix2pix_turbo.py:36,45;
+    the ``.fp16.safetensors`` variant is accepted).  Everything is widened to fp32: the packer rounds once, after the merge."""
     from safetensors.torch import load_file
     out = []
     for sub in ("unet", "vae"):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 2
+#define I2I_ABI_VERSION 3
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -49,7 +49,8 @@ typedef enum {
     I2I_OP_DDPM_POSTQUANT = 8,
     I2I_OP_ATTENTION = 9,
     I2I_OP_GN_APPLY = 10,
-    I2I_OP_EMBED = 11
+    I2I_OP_EMBED = 11,
+    I2I_OP_LORA_MERGE = 12
 } i2i_opcode;
 
 /* ---------------------------------------------------------------------------------------------
@@ -170,6 +171,8 @@ typedef struct {
 typedef struct {
     const void* moments; const float* eps; const float* noise; void* u;
     int32_t n, hw, lat, ldm, ldu, noise_n; float sf, r;
+    const float* r_dev; /* optional device scalar overriding `r` at run time (the program / hipGraph stays valid when the
+                           caller changes r: gradio_sketch2image.py sweeps it per request) */
     float* u_f32;      /* optional fp32 copy [n][hw][lat] for the scheduler step (keeps latent math fp32) */
     int32_t moments_f32; /* 1: moments are fp32 (producer igemm stored with out_f32) */
 } i2i_posterior_params;
@@ -181,6 +184,18 @@ typedef struct {
     int32_t n, hw, lat, ldu, lde, ldy; float sqrt_abar, sqrt_1m_abar, sf;
     int32_t u_f32, e_f32;  /* 1: that operand is fp32 (ldu/lde in fp32 elements) */
 } i2i_ddpm_params;
+
+/* Device-side LoRA re-merge into a packed weight tensor (peft's merged form; the reference keeps adapters as side branches
+ * and rescales them per call: unet.set_adapters(["default"], weights=[r]) / set_weights_and_activate_adapters(vae, ..., [r])
+ * src/pix2pix_turbo.py:206-207, decoder.gamma = r :217):
+ *   dst[n][k] = cvt( (w0[n][k] + r * sum_j b[n][j] * a[j][k]) * (use_gamma ? gamma : 1) ),  (r, gamma) = rg[0..1] on the device.
+ * w0 fp32 master in the packed layout, a fp32 [rank][K] with lora_alpha/rank folded in (adapters concatenated along rank),
+ * b fp32 [N][rank].  K multiple of 4.  rg = NULL means r = gamma = 1. */
+typedef struct {
+    void* dst; const float* w0; const float* a; const float* b;
+    int32_t N, K, rank, use_gamma;
+    const float* rg;
+} i2i_lora_merge_params;
 
 typedef struct {
     int32_t opcode;    /* i2i_opcode */
@@ -197,6 +212,7 @@ typedef struct {
         i2i_posterior_params posterior;
         i2i_ddpm_params ddpm;
         i2i_embed_params embed;
+        i2i_lora_merge_params lora_merge;
     } u;
 } i2i_op;
 
@@ -221,6 +237,7 @@ int i2i_nhwc_to_nchw(const i2i_nhwc_to_nchw_params* p, int dtype, void* stream);
 int i2i_posterior(const i2i_posterior_params* p, int dtype, void* stream);
 int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream);
 int i2i_embed(const i2i_embed_params* p, int dtype, void* stream);
+int i2i_lora_merge(const i2i_lora_merge_params* p, int dtype, void* stream);
 
 /* ---- programs: a forward pass is a flat array of ops executed in order on one stream ---- */
 int i2i_run(const i2i_op* ops, int n_ops, void* stream);

@@ -39,6 +39,23 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib):
 
 
 @pytest.mark.slow
+def test_pix2pix_r_sweep_one_plan_fp32(emu_lib):
+    """The per-request gamma sweep of gradio_sketch2image.py:67-91 on ONE model: every r re-merges the packed weights on the
+    device (no new packer, no new plan), and each output matches the oracle's unmerged-LoRA forward at that r."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
+    plans, packers = None, None
+    for r in (0.4, 1.0, 0.7, 0.4):
+        ref = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=r, noise_map=nm)
+        out = model(x, caption_enc=cap, eps=eps, deterministic=False, r=r, noise_map=nm)
+        assert (out - ref).abs().max().item() < 1e-3, r
+        if plans is None:
+            plans, packers = list(model._plans.values()), list(model._packers.values())
+        assert list(model._plans.values()) == plans and list(model._packers.values()) == packers
+
+
+@pytest.mark.slow
 def test_cyclegan_b2a_fp32(emu_lib):
     mw = make_cyclegan_weights(TINY_UNET, TINY_VAE, rank_unet=16)
     x, cap, eps, _ = make_inputs("photo", 1, 64, 64, TINY_UNET.cross_attention_dim)
@@ -47,6 +64,13 @@ def test_cyclegan_b2a_fp32(emu_lib):
     out = model(x, direction="b2a", caption_emb=cap, eps=eps)
     err = (out - ref).abs().max().item()
     assert err < 1e-3, err
+    # the static entry point the reference's callers use (src/cyclegan_turbo.py:199-207, src/train_cyclegan_turbo.py:181)
+    out2 = CycleGAN_Turbo.forward_with_networks(x, "b2a", model.vae_enc, model.unet, model.vae_dec, model.sched, model.timesteps, cap, eps=eps)
+    assert torch.equal(out, out2)
+    other = CycleGAN_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
+    with pytest.raises(ValueError):
+        CycleGAN_Turbo.forward_with_networks(x, "b2a", model.vae_enc, other.unet, model.vae_dec, model.sched, model.timesteps, cap)
+    assert any(k.startswith("vae_b2a.") for k in model.vae_enc.state_dict()) and any(k.startswith("vae.") for k in model.vae_dec.state_dict())
 
 
 @pytest.mark.slow

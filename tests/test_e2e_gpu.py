@@ -1,10 +1,15 @@
 """End-to-end parity on a real MI355X: Pix2Pix_Turbo / CycleGAN_Turbo forward through the C ABI vs the CPU
 oracle on the same seeded synthetic weights and inputs.
 
-Tolerances (max-abs on outputs clamped to [-1, 1]):
-  fp32 (exact-f32 MFMA)  1e-3   -- BASELINE.json's stated bound vs CPU fp32
-  bf16 / fp16            stated from measurement: the 1-step scheduler amplifies UNet error 14.6x before the
-                         decoder (SURVEY.md section 7 hard part 3), see DESIGN.md "Numerics".
+Tolerances (outputs clamped to [-1, 1]):
+  fp32 (exact-f32 MFMA)  max-abs 1e-3   -- BASELINE.json's stated bound vs CPU fp32 (measured ~2e-5)
+  bf16                   max-abs 0.15 AND PSNR >= 40 dB  (measured 0.088-0.096 / 43 dB: ~1.5x the measurement; the 1-step
+  fp16                   max-abs 0.03 AND PSNR >= 55 dB   scheduler amplifies UNet rounding 14.6x before the decoder, DESIGN.md
+                                                          "Numerics"; measured 0.012 / 61 dB)
+A dropped skip connection, a missing LoRA branch or a zeroed conv moves max-abs to O(1) and PSNR below 25 dB.
+
+The oracle is per-image independent (per-sample norms and attention), so the BASELINE-scale tests run the GPU at the full
+benchmarked batch and the CPU oracle on a SUBSET of the images (first and last), keeping the CPU time of the suite in minutes.
 """
 import pytest
 import torch
@@ -18,7 +23,8 @@ from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
 from img2img_turbo_amd.weights import GeneratorWeights
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float32: 1e-3, torch.bfloat16: 0.35, torch.float16: 0.08}
+TOL = {torch.float32: 1e-3, torch.bfloat16: 0.15, torch.float16: 0.03}
+PSNR_MIN = {torch.float32: 90.0, torch.bfloat16: 40.0, torch.float16: 55.0}
 
 
 def gw(mw):
@@ -33,6 +39,16 @@ def report(name, out, ref):
     return d.max().item()
 
 
+def check(name, out, ref, dtype):
+    """Both gates: max-abs (a single wrong pixel) and PSNR (a diffuse error such as a mis-scaled branch)."""
+    d = (out.float().cpu() - ref).abs()
+    mse = (d ** 2).mean().item()
+    psnr = 10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20))).item()
+    print(f"[parity] {name}: max-abs {d.max().item():.3e} mean-abs {d.mean().item():.3e} psnr {psnr:.1f} dB")
+    assert d.max().item() < TOL[dtype], (name, d.max().item())
+    assert psnr > PSNR_MIN[dtype], (name, psnr)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_tiny_pix2pix_deterministic(gpu_lib, dtype):
     mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
@@ -41,7 +57,7 @@ def test_tiny_pix2pix_deterministic(gpu_lib, dtype):
     for graph in (False, True):
         model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=dtype, use_graph=graph)
         out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
-        assert report(f"tiny pix2pix {dtype} graph={graph}", out, ref) < TOL[dtype]
+        check(f"tiny pix2pix {dtype} graph={graph}", out, ref, dtype)
         out2 = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
         assert torch.equal(out, out2), "forward is not run-to-run deterministic"
 
@@ -139,3 +155,110 @@ def test_full_sd_turbo_512(gpu_lib):
     e16 = report("SD-Turbo 512x512 bf16", out, ref)
     assert e32 < 1e-3
     assert e16 < TOL[torch.bfloat16]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configurations at their own scale (full SD-Turbo architecture, benchmarked batch sizes and dtypes)
+# ---------------------------------------------------------------------------------------------------------------
+def _free(*objs):
+    for o in objs:
+        if hasattr(o, "release_plans"):
+            o.release_plans()
+    torch.cuda.empty_cache()
+
+
+def test_cfg2_pix2pix_bf16_bs8_512(gpu_lib):
+    """configs[1], the benchmarked configuration: edge_to_image, bf16, bs=8, 512x512 through the hipGraph path.
+    Oracle on images 0 and 7; the batch slots in between are covered by the slot-consistency check (image 0 fed again in
+    slot 5 must come out bit-identical: the kernels are deterministic and per-image independent) and by the fp32 route check:
+    bs=8 and bs=1 take different kernels for some convs (halo_min_tiles) and must agree to fp32 round-off."""
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 2)
+    x, cap, eps, _ = make_inputs("canny", 8, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=2)
+    x[5], eps[5] = x[0], eps[0]
+    ref = pix2pix_forward(mw, x[[0, 7]], cap, eps[[0, 7]])
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    check("cfg2 pix2pix bf16 bs=8 512x512 (images 0,7)", out[[0, 7]], ref, torch.bfloat16)
+    assert torch.equal(out[0], out[5]), "same image in another batch slot must give the same bits"
+    _free(model)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
+    out8 = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    check("cfg2 fp32 bs=8 (images 0,7)", out8[[0, 7]], ref, torch.float32)
+    out1 = model(x[7:8].cuda(), caption_enc=cap.cuda(), eps=eps[7:8].cuda())
+    d = (out8[7:8] - out1).abs().max().item()
+    print(f"[parity] fp32 route agreement bs=8 vs bs=1: {d:.3e}")
+    assert d < 2e-4, d
+    _free(model)
+
+
+@pytest.mark.parametrize("direction", ["a2b", "b2a"])
+def test_cfg3_cyclegan_bf16_bs4_512(gpu_lib, direction):
+    """configs[2] per-GPU share: CycleGAN-Turbo (UNet LoRA rank 128 x 3 adapters, two VAEs), bf16, 4 images / GPU, 512x512,
+    both directions; oracle = unmerged rank-128 LoRA on image 0 and 3.  Also the static forward_with_networks entry."""
+    mw = make_cyclegan_weights(SD_TURBO_UNET, SD_TURBO_VAE)
+    x, cap, eps, _ = make_inputs("photo", 4, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=3)
+    ref = cyclegan_forward(mw, x[[0, 3]], cap, eps[[0, 3]], direction=direction)
+    model = CycleGAN_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+    out = CycleGAN_Turbo.forward_with_networks(x.cuda(), direction, model.vae_enc, model.unet, model.vae_dec, model.sched,
+                                               model.timesteps, cap.cuda(), eps=eps.cuda())
+    check(f"cfg3 cyclegan {direction} bf16 bs=4 512x512 (images 0,3)", out[[0, 3]], ref, torch.bfloat16)
+    _free(model)
+
+
+def test_cfg4_stochastic_bf16_bs16_512(gpu_lib):
+    """configs[3]: sketch_to_image_stochastic, gamma = 0.4, bs=16, bf16: TwinConv, noise interpolation, every LoRA scale and
+    the skip gamma x r (src/pix2pix_turbo.py:204-218) -- here one device-side re-merge.  A second r on the same model must
+    also match (the slider of gradio_sketch2image.py), and returning to r = 0.4 must reproduce the first output bit for bit."""
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 4, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 16, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=4)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+    xs, ns, es = x.cuda(), nm.cuda(), eps.cuda()
+    ref = pix2pix_forward(mw, x[[0, 15]], cap, eps[[0, 15]], deterministic=False, r=0.4, noise_map=nm[[0, 15]])
+    out = model(xs, caption_enc=cap.cuda(), eps=es, deterministic=False, r=0.4, noise_map=ns)
+    check("cfg4 stochastic r=0.4 bf16 bs=16 (images 0,15)", out[[0, 15]], ref, torch.bfloat16)
+    ref1 = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.8, noise_map=nm[:1])
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.set_lora_scale(0.8)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    print(f"[timing] device-side LoRA re-merge of the whole model (UNet + VAE): {dt:.1f} ms")
+    assert dt < 50.0, dt
+    out1 = model(xs, caption_enc=cap.cuda(), eps=es, deterministic=False, r=0.8, noise_map=ns)
+    check("cfg4 stochastic r=0.8 after re-merge (image 0)", out1[:1], ref1, torch.bfloat16)
+    out2 = model(xs, caption_enc=cap.cuda(), eps=es, deterministic=False, r=0.4, noise_map=ns)
+    assert torch.equal(out, out2), "r=0.4 -> 0.8 -> 0.4 must reproduce the first output exactly"
+    assert len(model._plans) == 1 and len(model._packers) == 2
+    _free(model)
+
+
+def test_cfg5_pix2pix_fp16_1024(gpu_lib):
+    """configs[4] correctness at its own resolution: 1024x1024 fp16 (T = 16384 tokens through the d=512 wide-head attention
+    and the d=64 UNet attention, 1024^2 halo planes), GPU batch 2, oracle on image 1."""
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 5)
+    x, cap, eps, _ = make_inputs("canny", 2, 1024, 1024, SD_TURBO_UNET.cross_attention_dim, seed=5)
+    ref = pix2pix_forward(mw, x[1:2], cap, eps[1:2])
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float16)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    check("cfg5 pix2pix fp16 bs=2 1024x1024 (image 1)", out[1:2], ref, torch.float16)
+    _free(model)
+
+
+def test_plan_cache_is_bounded(gpu_lib):
+    """Sweeping image sizes must not grow HBM without bound: the plan cache is an LRU that destroys the evicted plan's
+    hipGraph and drops its activation pool."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+    model.MAX_PLANS = 3
+    cap = torch.randn(1, 77, TINY_UNET.cross_attention_dim).cuda()
+    first = None
+    for k in range(8):
+        hw = 64 + 8 * k
+        x = torch.rand(1, 3, hw, hw).cuda()
+        out = model(x, caption_enc=cap, eps=torch.zeros(1, 4, hw // 8, hw // 8).cuda())
+        first = out if first is None else first
+        assert len(model._plans) <= 3
+    again = model(torch.rand(1, 3, 64, 64).cuda(), caption_enc=cap, eps=torch.zeros(1, 4, 8, 8).cuda())   # evicted size is re-planned
+    assert again.shape == first.shape
+    _free(model)

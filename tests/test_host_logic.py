@@ -74,10 +74,12 @@ def test_cyclegan_checkpoint_roundtrip(tmp_path):
     assert gw.unet_scaling == {"default_encoder": 1.0, "default_decoder": 1.0, "default_others": 1.0}
 
 
-def test_packer_merge_and_layouts():
+def test_packer_merge_and_layouts(emu_lib):
+    """Layouts + the DEVICE-side LoRA merge (csrc/lora_merge.hip, here on the emulator twin) against the oracle's host merge,
+    at r = 0.4 from the start and again after set_scale() moved r."""
     mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=6)
     r = 0.4
-    pk = Packer(mw.vae, mw.vae_scaling, torch.float32, "cpu", r)
+    pk = Packer(mw.vae, mw.vae_scaling, torch.float32, "cpu", emu_lib, r, r)
     W = Weights(mw.vae, {k: v * r for k, v in mw.vae_scaling.items()})
     name = "decoder.up_blocks.2.resnets.0.conv1"
     wm, bm = W.merged(name)
@@ -98,7 +100,7 @@ def test_packer_merge_and_layouts():
     wfold = eo["w"].view(8, 3, 3, -1).permute(0, 3, 1, 2)
     assert torch.allclose(torch.nn.functional.conv2d(x, wfold, eo["b"], padding=1), ref, atol=1e-4)
     # GEGLU interleave: packed row blocks are [16 value | 16 gate]
-    pu = Packer(mw.unet, mw.unet_scaling, torch.float32, "cpu", 1.0)
+    pu = Packer(mw.unet, mw.unet_scaling, torch.float32, "cpu", emu_lib, 1.0, 1.0)
     nm = "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj"
     wg, bg = Weights(mw.unet, mw.unet_scaling).merged(nm)
     gp = pu.geglu_linear(nm)
@@ -154,3 +156,135 @@ def test_data_parallel_two_process_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_OK" in outs[0]
+
+
+def _unpack_conv(pw, ks):
+    w = pw["w"].float()
+    return w.view(w.shape[0], ks, ks, -1).permute(0, 3, 1, 2)
+
+
+def test_device_lora_remerge_r_sweep(emu_lib):
+    """set_scale(r) must leave every packed layer equal to the oracle's host merge at that r: plain convs, the sub-pixel
+    upsampler form (linear in the 3x3 kernel), stacked q|k rows, GEGLU-interleaved rows, conv_out o quant_conv, the skip
+    convs (which also carry gamma) and the TwinConv fold -- in place, same device addresses (src/pix2pix_turbo.py:206-217)."""
+    from img2img_turbo_amd.packer import subpixel_weights
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=9, sketch=True)
+    for dtype, tol in ((torch.float32, 2e-6), (torch.bfloat16, 1.0 / 128)):
+        pv = Packer(mw.vae, mw.vae_scaling, dtype, "cpu", emu_lib)
+        pu = Packer(mw.unet, mw.unet_scaling, dtype, "cpu", emu_lib)
+        names = dict(conv="decoder.up_blocks.1.resnets.0.conv1", up="decoder.up_blocks.0.upsamplers.0.conv", skip="decoder.skip_conv_2",
+                     q="down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q", k="down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_k",
+                     ff="down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj")
+        got = dict(conv=pv.conv(names["conv"]), up=pv.conv_subpixel(names["up"]), skip=pv.conv(names["skip"], gamma=True),
+                   enc=pv.encoder_out(), qk=pu.stacked_linear([names["q"], names["k"]]), ff=pu.geglu_linear(names["ff"]), twin=pu.twin_conv_in())
+        ptrs = {k: v["w"].data_ptr() for k, v in got.items()}
+        for r in (1.0, 0.4, 0.0, 0.73, 1.0):
+            pv.set_scale(r)
+            pu.set_scale(r)
+            Wv = Weights(mw.vae, {k: v * r for k, v in mw.vae_scaling.items()})
+            Wu = Weights(mw.unet, {k: v * r for k, v in mw.unet_scaling.items()})
+
+            def close(a, b, what):
+                assert torch.allclose(a.float(), b, atol=tol * max(1.0, float(b.abs().max())), rtol=0), (what, r, dtype, float((a.float() - b).abs().max()))
+            close(_unpack_conv(got["conv"], 3), Wv.merged(names["conv"])[0], "conv")
+            wu = Wv.merged(names["up"])[0]
+            close(got["up"]["w"], subpixel_weights(wu).reshape(4 * wu.shape[0], -1), "subpixel")
+            close(_unpack_conv(got["skip"], 1), Wv.merged(names["skip"])[0] * r, "skip*gamma")
+            wc, bc = Wv.merged("encoder.conv_out")
+            wq = Wv.merged("quant_conv")[0][:, :, 0, 0]
+            close(_unpack_conv(got["enc"], 3), torch.einsum("po,oiyx->piyx", wq, wc), "conv_out o quant_conv")
+            close(got["qk"]["w"], torch.cat([Wu.merged(names["q"])[0], Wu.merged(names["k"])[0]], 0), "q|k")
+            wf = Wu.merged(names["ff"])[0]
+            half = wf.shape[0] // 2
+            close(got["ff"]["w"][:16], wf[:16], "geglu value rows")
+            close(got["ff"]["w"][16:32], wf[half:half + 16], "geglu gate rows")
+            w1, w2 = Wu.merged("conv_in.conv_in_pretrained")[0], Wu.merged("conv_in.conv_in_curr")[0]
+            tw = _unpack_conv(got["twin"], 3)[:, :w1.shape[1]]
+            close(tw, w1 * (1 - r) + w2 * r, "TwinConv")
+        assert ptrs == {k: v["w"].data_ptr() for k, v in got.items()}, "a re-merge must not move the packed tensors"
+
+
+def test_save_model_roundtrip_and_handles(tmp_path, emu_lib):
+    """Pix2Pix_Turbo.save_model writes the reference's dict (src/pix2pix_turbo.py:221-229) and it loads back to the same
+    canonical weights; the module exposes the attributes callers touch (.unet, .vae, .sched, .timesteps)."""
+    from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
+    from img2img_turbo_amd.weights import GeneratorWeights
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=5)
+    base_unet, base_vae, ckpt = split_pix2pix_checkpoint(mw)
+    gw = from_pix2pix_checkpoint(base_unet, base_vae, ckpt, TINY_UNET, TINY_VAE)
+    model = Pix2Pix_Turbo(weights=gw, device="cpu", dtype=torch.float32, lib=emu_lib)
+    assert model.lora_rank_unet == ckpt["rank_unet"] and model.target_modules_vae == ckpt["vae_lora_target_modules"]
+    f = tmp_path / "model_1001.pkl"
+    model.save_model(f)
+    sd = load_checkpoint_file(f)
+    assert set(sd) == {"unet_lora_target_modules", "vae_lora_target_modules", "rank_unet", "rank_vae", "state_dict_unet", "state_dict_vae"}
+    _same(sd["state_dict_unet"], ckpt["state_dict_unet"])
+    _same(sd["state_dict_vae"], ckpt["state_dict_vae"])
+    gw2 = from_pix2pix_checkpoint(base_unet, base_vae, sd, TINY_UNET, TINY_VAE)
+    _same(gw2.unet, mw.unet)
+    _same(gw2.vae, mw.vae)
+    assert set(model.unet.state_dict()) == set(mw.unet) and set(model.vae.state_dict()) == set(mw.vae)
+    assert model.unet.enable_xformers_memory_efficient_attention() is None and model.set_eval() is model
+    assert model.timesteps.tolist() == [999]
+    with pytest.raises(NotImplementedError):
+        model.set_train()
+
+
+def test_load_sd_turbo_base_from_safetensors(tmp_path):
+    """Row f4: the SD-Turbo snapshot reader on synthetic safetensors files laid out as ``from_pretrained(subfolder=...)``
+    expects them -- fp32 and the ``.fp16`` variant, and the legacy VAE attention key names (query/key/value/proj_attn with
+    [C, C, 1, 1] conv-style weights in old checkpoints are NOT assumed: diffusers renames linear-shaped tensors)."""
+    from safetensors.torch import save_file
+    from img2img_turbo_amd.weights import load_sd_turbo_base
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=3)
+    base_unet, base_vae, _ = split_pix2pix_checkpoint(mw)
+    base_vae = {k: v for k, v in base_vae.items() if "skip_conv" not in k}          # the hub VAE has no skip convs
+    legacy = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    vae_legacy = {}
+    for k, v in base_vae.items():
+        for new, old in legacy.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+        vae_legacy[k] = v.contiguous()
+    assert any(".query." in k for k in vae_legacy)
+    for variant, cast in (("", torch.float32), (".fp16", torch.float16)):
+        root = tmp_path / ("snap" + variant)
+        (root / "unet").mkdir(parents=True)
+        (root / "vae").mkdir()
+        save_file({k: v.to(cast).contiguous() for k, v in base_unet.items()}, str(root / "unet" / f"diffusion_pytorch_model{variant}.safetensors"))
+        save_file({k: v.to(cast) for k, v in vae_legacy.items()}, str(root / "vae" / f"diffusion_pytorch_model{variant}.safetensors"))
+        unet, vae = load_sd_turbo_base(str(root))
+        assert set(unet) == set(base_unet) and set(vae) == set(base_vae)
+        tol = 0 if cast == torch.float32 else 1e-3
+        for k in base_unet:
+            assert unet[k].dtype == torch.float32 and torch.allclose(unet[k], base_unet[k], atol=tol, rtol=tol), k
+        for k in base_vae:
+            assert torch.allclose(vae[k], base_vae[k], atol=tol, rtol=tol), k
+    with pytest.raises(FileNotFoundError):
+        load_sd_turbo_base(str(tmp_path / "nowhere"))
+
+
+def test_pretrained_name_constructor_with_local_snapshot(tmp_path, emu_lib, monkeypatch):
+    """``Pix2Pix_Turbo(pretrained_name="edge_to_image")`` as written in src/inference_paired.py:31 works once
+    I2I_SD_TURBO_DIR points at a local snapshot and ckpt_folder holds the .pkl (the reference downloads both)."""
+    from safetensors.torch import save_file
+    from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
+    import img2img_turbo_amd.pix2pix_turbo as P
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=4)
+    base_unet, base_vae, ckpt = split_pix2pix_checkpoint(mw)
+    root = tmp_path / "sd-turbo"
+    (root / "unet").mkdir(parents=True)
+    (root / "vae").mkdir()
+    save_file({k: v.contiguous() for k, v in base_unet.items()}, str(root / "unet" / "diffusion_pytorch_model.safetensors"))
+    save_file({k: v.contiguous() for k, v in base_vae.items() if "skip_conv" not in k}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    ck = tmp_path / "checkpoints"
+    ck.mkdir()
+    torch.save(ckpt, ck / "edge_to_image_loras.pkl")
+    monkeypatch.setenv("I2I_SD_TURBO_DIR", str(root))
+    monkeypatch.setattr(P, "from_pix2pix_checkpoint", lambda u, v, c: from_pix2pix_checkpoint(u, v, c, TINY_UNET, TINY_VAE))
+    model = Pix2Pix_Turbo(pretrained_name="edge_to_image", ckpt_folder=str(ck), device="cpu", dtype=torch.float32, lib=emu_lib)
+    _same(model.weights.unet, mw.unet)
+    _same(model.weights.vae, mw.vae)
+    monkeypatch.delenv("I2I_SD_TURBO_DIR")
+    with pytest.raises(ValueError):
+        Pix2Pix_Turbo(pretrained_name="edge_to_image", ckpt_folder=str(ck), device="cpu", lib=emu_lib)
