@@ -411,11 +411,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
     constexpr int KC = D / 32, DF = D / 16;         // k-chunks over d (S^T), output fragments over d (O^T)
     constexpr int KTILE = BKV * D * 2, VTILE = D * 64, STAGE = KTILE + VTILE;
     constexpr int OPS = (BKV + D / 16) / NW;        // one-KiB DMA ops per wave and stage
-#ifdef I2I_GLDS_ASM
-    constexpr int LOOK = 2;                         // experiment build: counted lgkm waits, and 2 keeps the kernel spill-free
-#else
     constexpr int LOOK = 4;                         // fragment reads in flight ahead of the MFMAs that consume them
-#endif
     constexpr int BQ = NW * QF * 16;                // queries per workgroup
     static_assert((BKV + D / 16) % NW == 0, "");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -449,21 +445,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
                 int key = kv0 + pc;
                 key = key < p.tk ? key : p.tk - 1;
                 const unsigned sc = (unsigned)(ln ^ (pc & 15));          // source chunk of physical chunk `lane` (att_off<CPRK>)
-#ifdef I2I_GLDS_ASM
-                glds16_sv(kp, ((unsigned)key * (unsigned)p.ldk + sc * 8u) * (unsigned)sizeof(T), dst + pc * 1024);
-#else
                 glds16(kp + ((unsigned)key * (unsigned)p.ldk + sc * 8u) * (unsigned)sizeof(T), dst + pc * 1024);
-#endif
             } else {
                 const int row = (pc - BKV) * 16 + (ln >> 2);
                 const int sc = (ln & 3) ^ ((row >> 2) & 3);
                 int key0 = kv0 + sc * 8;
                 key0 = key0 < p.tk ? key0 : 0;
-#ifdef I2I_GLDS_ASM
-                glds16_sv(vp, ((unsigned)row * (unsigned)p.ldvt + (unsigned)key0) * (unsigned)sizeof(T), dst + pc * 1024);
-#else
                 glds16(vp + ((unsigned)row * (unsigned)p.ldvt + (unsigned)key0) * (unsigned)sizeof(T), dst + pc * 1024);
-#endif
             }
         }
     };
@@ -520,21 +508,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
         for (int f = 0; f < QF; ++f) sacc[f][0] = sacc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             // explicit software pipeline: fragment n = (kc = n>>1, kf = n&1) is read LOOK fragments before its MFMAs
-#ifdef I2I_GLDS_ASM
-            int kb0 = kb[0];
-#ifndef I2I_EMU
-            asm volatile("" : "+v"(kb0));        // opaque per tile: keeps hipcc from re-materialising all four bases in registers
-#endif
-#endif
             auto kread = [&](int n) __attribute__((always_inline)) -> chunk_t {
                 const int kc = n >> 1, kf = n & 1;
-#ifdef I2I_GLDS_ASM
-                // experiment build: ONE base register; bits 6-7 of kb[] are the only ones that differ between the four bases
-                // (kb[j] = kb[0] ^ (j << 6)), which frees the three VGPRs whose absence made the product build spill
-                return *(const chunk_t*)(Ks + ((kb0 ^ ((kc & 3) << 6)) + kf * 16 * CPRK * 16 + (kc >> 2) * 256));
-#else
                 return *(const chunk_t*)(Ks + (kb[kc & 3] + kf * 16 * CPRK * 16 + (kc >> 2) * 256));
-#endif
             };
             chunk_t fr[LOOK];
             __builtin_amdgcn_sched_barrier(0);

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_pst.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
 HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
 LIB = os.path.join(HERE, "libi2i_turbo.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -40,7 +40,7 @@ def _compile(src, force, bdir="build", defs=()):
 
 def build(force=False, jobs=None, tag=None, defs=()):
     """tag/defs: an EXPERIMENT build next to the product one (libi2i_turbo_<tag>.so, objects in build_<tag>/), e.g.
-    ``build.py --tag glds_asm --defs=-DI2I_GLDS_ASM=1``; load it with I2I_LIB=<path> (img2img_turbo_amd._capi)."""
+    ``build.py --tag trace --defs=-DI2I_TRACE=1`` (the halo conv's cycle tracer); load it with I2I_LIB=<path> (img2img_turbo_amd._capi)."""
     bdir = "build" + ("_" + tag if tag else "")
     lib = LIB if not tag else os.path.join(HERE, "libi2i_turbo_%s.so" % tag)
     os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
@@ -59,6 +59,6 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", type=int, default=None)
     ap.add_argument("--tag", default=None, help="experiment build: libi2i_turbo_<tag>.so")
-    ap.add_argument("--defs", default="", help="extra hipcc flags of the experiment build, e.g. -DI2I_GLDS_ASM=1")
+    ap.add_argument("--defs", default="", help="extra hipcc flags of the experiment build, e.g. -DI2I_TRACE=1")
     a = ap.parse_args()
     print(build(a.force, a.j, a.tag, a.defs.split()))

@@ -115,9 +115,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     constexpr int BS0 = DBH ? 0 : HALO * 128;                        // [RING][BN] rows of 128 B
     constexpr int HS0 = DBH ? RING * BN * 128 : 0;                   // [1 or 2][HALO] rows of 128 B (one slab each)
     constexpr int SS0 = DBH ? HS0 + 2 * HALO * 128 : BS0 + RING * BN * 128;   // [1 or 2][CK][2] fp32 (scale, shift)
+    constexpr int BI0 = SS0 + (DBH ? 1024 : 512);                    // [BN] fp32 bias of this channel tile
     char* Hs = i2i_smem + HS0;
     char* Bs = i2i_smem + BS0;
     char* Ss = i2i_smem + SS0;
+    // The per-channel bias of the tile rides into LDS with the prologue's DMA batch: the epilogue then has no global load to
+    // wait for (a bias load issued there sits a full L2 round trip -- ~7 % of a 2-slab tile -- on the critical path).
+    const bool bias_lds = p.bias_mode == 1 && (p.N & 3) == 0;
     int hcur = 0;                                    // DBH: halo image / constant block of the slab being multiplied
 
     // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
@@ -143,13 +147,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     }
     const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
     const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
-    // pixel pitches in bytes, pinned in VGPRs: left to itself hipcc re-reads the selected kernarg field with an
-    // s_load_dword + lgkmcnt(0) in every tap window (scalar-cache latency on the critical path of each step)
-    // (I2I_GLDS_ASM experiment build only, together with the hidden LDS-DMA: not yet measured on hardware)
-    unsigned ld0_b = (unsigned)p.lda0 * (unsigned)sizeof(T), ld1_b = (unsigned)p.lda1 * (unsigned)sizeof(T);
-#if defined(I2I_GLDS_ASM) && !defined(I2I_EMU)
-    asm volatile("" : "+v"(ld0_b), "+v"(ld1_b));
-#endif
 
     // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3),
     // physical chunk lane&7, i.e. source chunk (lane&7) ^ swz(row).  Rows past N are clamped (their
@@ -185,11 +182,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
         const int ci = slab * CK;                                       // wave-uniform source select
         const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
-#ifdef I2I_GLDS_ASM
-        const unsigned ldb = ci < p.c0 ? ld0_b : ld1_b;
-#else
         const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
-#endif
         const unsigned pix = (hpix[j] == ~0u) ? 0u : hpix[j];
         const unsigned voff = pix * ldb + (unsigned)kc * 16u;
         if (hidden) gload16_uncounted(rh[j], base, voff);
@@ -242,18 +235,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #pragma unroll
     for (int t = 0; t < RING; ++t) b_dma(0, t, t);
     if (has_gn) ss_dma(0, 0);
+    if (bias_lds && wave == NW - 1 && lane < BN / 4) {
+        int n = n0 + lane * 4;
+        n = n + 4 <= p.N ? n : p.N - 4;                  // lanes past a ragged tile's end re-read its last quad (never stored)
+        glds16(p.bias + n, i2i_smem + BI0);
+    }
 #pragma unroll
     for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
     I2I_TR(8);
     wait_vmcnt<0>();
     I2I_TR(9);
-    // I2I_GLDS_ASM build: retire these loads in hipcc's own bookkeeping on EVERY path, here: their consumers below sit in
-    // per-lane conditionals, and a load the compiler still considers pending on the skipped path gets a vmcnt wait at the
-    // first reuse of its register -- inside the slab loop, draining the (then invisible) DMA ring there
-#ifdef I2I_GLDS_ASM
-#pragma unroll
-    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
-#endif
     lds_barrier();
     I2I_TR(10);
     halo_store_all();
@@ -489,8 +480,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
                 const int n = n0 + wn * WTN + cw;
                 gquad[2 * jp] = cw >> 2; gquad[2 * jp + 1] = (cw >> 2) + 1;
                 float bv[8];
+                if (bias_lds) {
+                    const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + cw) * 4), b1 = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + cw + 4) * 4);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N && !I2I_ABL(2)) ? p.bias[n + r] : 0.f;
+                    for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) bv[r] = (p.bias_mode == 1 && n < p.N && !I2I_ABL(2)) ? p.bias[n + r] : 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     float v[8];
@@ -525,7 +522,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             const int n = n0 + wn * WTN + j * 16 + lqc * 4;
             gquad[j] = j * 4 + lqc;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias_mode == 1) {
+            if (bias_lds) {
+                const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 16 + lqc * 4) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = b0[r];
+            } else if (p.bias_mode == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
             }
@@ -625,7 +626,7 @@ int launch_halo(const i2i_igemm_params& p, hipStream_t s) {
     constexpr int KS = SUBPIX ? 2 : 3, RING = (SUBPIX || DBH) ? 2 : 3;
     const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
     const unsigned tiles = (unsigned)(((pl_w + TW - 1) / TW) * ((pl_h + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN)) * (SUBPIX ? 4u : 1u);
-    const size_t smem = ((DBH ? 2 : 1) * (TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + (DBH ? 1024 : 512);
+    const size_t smem = ((DBH ? 2 : 1) * (TH + KS - 1) * (TW + KS - 1) + RING * BN) * 128 + (DBH ? 1024 : 512) + BN * 4;
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, WM, WN, PD, MINW, SUBPIX, DBH>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
     return i2i::check_launch("conv3x3_halo");
 }
@@ -716,20 +717,7 @@ int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     if (cpg % 4 || wtn % cpg) return 0;
     return ((p.wo + TW - 1) / TW) * ((p.ho + th - 1) / th);
 }
-#ifdef I2I_PST_CONV
-int conv3x3_pst(const i2i_igemm_params& p, int dtype, int cfg, hipStream_t s);    // conv3x3_pst.hip (experiment build)
-bool conv3x3_pst_worthwhile(const i2i_igemm_params& p, int bn);
-#endif
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s) {
-#ifdef I2I_PST_CONV
-    if (!p.subpix) {
-        const int cfg = halo_cfg(p);
-        if (cfg == 43 || cfg == 44 || cfg == 47) return conv3x3_pst(p, dtype, cfg, s);
-        if ((p.tile == 0 || p.tile == 10) && (cfg == 13 || cfg == 17) && conv3x3_pst_worthwhile(p, 128))
-            return conv3x3_pst(p, dtype, cfg == 17 ? 47 : 43, s);
-        if ((p.tile == 0 || p.tile == 10) && cfg == 34 && conv3x3_pst_worthwhile(p, 256)) return conv3x3_pst(p, dtype, 44, s);
-    }
-#endif
     switch (dtype) {
         case I2I_F32: return launch_halo_t<float>(p, s);
         case I2I_BF16: return launch_halo_t<__bf16>(p, s);

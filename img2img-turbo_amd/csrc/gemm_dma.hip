@@ -224,13 +224,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     // outputs with an even fragment count are widened to 8 consecutive n per lane (widen_pair, 16-byte stores)
     // Returns the number of store instructions this wave is GUARANTEED to have issued (0 = unknown): the persistent
     // stream adds it to its counted vmcnt so the next barrier does not wait for the stores to be acknowledged.
-#ifdef I2I_GLDS_ASM
-    // experiment build: lane ids enter the epilogue through an opaque copy, so hipcc recomputes the per-lane output offsets
-    // per tile instead of hoisting them out of the persistent tile loop into ~60 registers (the loop then spills)
-    auto epilogue_body = [&](int m0, int n0, int slot, int lr, int lq) __attribute__((always_inline)) -> int {
-#else
     auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
-#endif
     const bool exact = m0 + BM <= p.M && n0 + BN <= p.N;
     const int lqc = PERM ? frag_quad_of_lane(lq) : lq;
     const int64_t c_off = (int64_t)zb * p.c_bs_b + (int64_t)zh * p.c_bs_h;
@@ -293,14 +287,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     }
     const bool wide = PERM && !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!res || p.ldr % 8 == 0) &&
                       (((c_off | r_off) & 7) == 0) && (((uintptr_t)p.res & 15) == 0);
-#ifdef I2I_GEMM_GNPART
     // GroupNorm partial sums of the stored output (next layer's norm), as in conv3x3.hip: per lane and 4-channel quad,
     // then 16 rows (shuffles) -> wave (LDS) -> workgroup -> one slot per (image, row tile, group).  Wide path only (host check).
     const bool do_stats = p.gn_part != nullptr;
     float gs[FN], gq[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
-#endif
     if (wide) {
         if constexpr (PERM) {
             // residual chunks first, all in flight together (the compiler cannot hoist them over the stores itself)
@@ -347,7 +339,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
                     *(chunk_t*)((T*)p.c + c_off + (int64_t)m * p.ldc + n) = o;
-#ifdef I2I_GEMM_GNPART
                     if (do_stats) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
@@ -355,10 +346,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                             gs[2 * jp + (r >> 2)] += f; gq[2 * jp + (r >> 2)] += f * f;
                         }
                     }
-#endif
                 }
             }
-#ifdef I2I_GEMM_GNPART
             if (do_stats) {
                 // quad index inside the wave's channel span of accumulator slot (2*jp + h): channel = (2*jp + (lq>>1))*16 + (lq&1)*8 + 4*h
 #pragma unroll
@@ -398,7 +387,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 }
                 // (a persistent stream reuses the scratch: the barrier ahead of the next tile's writes orders them after these reads)
             }
-#endif
         }
         if (exact) note_vmem(FM * (FN / 2));
         return exact ? FM * (FN / 2) : 0;
@@ -449,15 +437,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     }
     return 0;
     };
-#ifdef I2I_GLDS_ASM
-    auto epilogue = [&](int m0, int n0, int slot) __attribute__((always_inline)) -> int {
-        int lr_o = lr, lq_o = lq;
-#ifndef I2I_EMU
-        asm volatile("" : "+v"(lr_o), "+v"(lq_o));
-#endif
-        return epilogue_body(m0, n0, slot, lr_o, lq_o);
-    };
-#endif
 
     // One K step.  `cur` = ring slot of the step (runtime: ONE copy of the step in the instruction stream).  The DMA
     // batch of step s+3 (B_s) goes out right after P_s and is waited for at P_{s+2} with a counted vmcnt that leaves
@@ -580,11 +559,7 @@ unsigned persist_wgs(unsigned resident) {
     return e ? (unsigned)atoi(e) : resident;
 }
 
-#ifdef I2I_GEMM_GNPART
 constexpr size_t GNP_LDS = 2048;      // [NW <= 8][FN*4 <= 16 quads][2] floats of GroupNorm partial scratch
-#else
-constexpr size_t GNP_LDS = 0;
-#endif
 
 template <typename T, int BM, int BN, int WM, int WN, int MINW>
 int launch_dma(const i2i_igemm_params& p, hipStream_t s) {
@@ -660,7 +635,6 @@ bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
 // GroupNorm partial-sum slots per image the LDS-DMA igemm writes for this op (0 = it cannot): 16-bit wide-store path, one
 // z, no split-K / GEGLU, row tiles that do not straddle images, channels-per-group a multiple of 4 dividing a wave's span.
 int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
-#ifdef I2I_GEMM_GNPART
     if (!igemm_dma_eligible(p, dtype) || dtype == I2I_F32 || p.out_f32 || p.geglu || p.splitk > 1 || p.zcount > 1) return 0;
     if (groups < 1 || p.N % groups || p.N % 8 || p.ldc % 8 || (p.res && p.ldr % 8) || ((uintptr_t)p.res & 15)) return 0;
     int bm, wtn;
@@ -675,10 +649,6 @@ int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     const int cpg = p.N / groups, hw = p.ho * p.wo;
     if (cpg % 4 || wtn % cpg || hw % bm) return 0;
     return hw / bm;
-#else
-    (void)p; (void)dtype; (void)groups;
-    return 0;
-#endif
 }
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     switch (dtype) {

@@ -128,35 +128,11 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // global_load_lds_dwordx4: 16 bytes per lane, global address per lane, LDS destination = wave-uniform base
 // + lane * 16 (M0); no VGPR round trip, no ds_write.
-#ifdef I2I_GLDS_ASM
-// Hidden form (cdna_hip_programming.md 5.7, glds16_asm): hipcc models the builtin as a FLAT access that may touch LDS
-// ("pending flat"), and while ONE such op is outstanding -- always, in a ring that keeps a batch in flight -- it turns every
-// LDS dependency wait into a full s_waitcnt lgkmcnt(0): the fragment read-ahead of the MFMA loops collapses to the reads of
-// the current row group.  Issued from an asm statement the DMA is invisible to that bookkeeping (the counted vmcnt waits are
-// hand-written anyway) and the ds_read waits become counted (lgkmcnt(N)).  M0 is saved and restored inside the statement.
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-}
-// same, source = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: one address VGPR instead of two
-__device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-    const uint64_t b = (uint64_t)(uintptr_t)sbase;
-    const uint64_t ub = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(ub), "s"(dst) : "memory");
-}
-#else
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, void* lds_wave_base) { glds16(sbase + voff, lds_wave_base); }
-#endif
 #endif
 // A 16-byte global load hipcc does NOT count (cdna_hip_programming.md 5.7 form (ii)): beside an LDS-DMA pipeline
 // the compiler drains vmcnt(0) before/after every ordinary VGPR load it can see, which would serialise the DMA

@@ -18,16 +18,12 @@ _EMU_BUILDS = {}
 
 
 def _emu_builds():
-    """Both emulator libraries, compiled CONCURRENTLY on first use (a cold build is minutes of host clang per library; the
-    objects are cached in tests/emu/build*/, so this only matters after a kernel source changed)."""
+    """The emulator library, compiled on first use (a cold build is minutes of host clang; the objects are cached in
+    tests/emu/build/, so this only matters after a kernel source changed)."""
     if not _EMU_BUILDS:
-        import concurrent.futures as cf
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         import build_emu
-        with cf.ThreadPoolExecutor(max_workers=2) as ex:
-            main = ex.submit(build_emu.build)
-            nxt = ex.submit(build_emu.build, "next", ["-DI2I_GLDS_ASM=1"])
-            _EMU_BUILDS["main"], _EMU_BUILDS["next"] = main.result(), nxt.result()
+        _EMU_BUILDS["main"] = build_emu.build()
     return _EMU_BUILDS
 
 
@@ -36,16 +32,6 @@ def emu_lib():
     """CPU emulator twin of the HIP library (tests/emu/): same kernel sources, host clang."""
     from img2img_turbo_amd import _capi
     lib = _capi.Library(_emu_builds()["main"])
-    assert lib.backend == "emu"
-    return lib
-
-
-@pytest.fixture(scope="session")
-def emu_lib_next():
-    """Emulator twin of the EXPERIMENT build's source variants (-DI2I_GLDS_ASM=1: the inline asm itself is compiled out under
-    I2I_EMU, the C++ that differs around it -- addressing, read-ahead depth, fences -- is what gets checked)."""
-    from img2img_turbo_amd import _capi
-    lib = _capi.Library(_emu_builds()["next"])
     assert lib.backend == "emu"
     return lib
 

@@ -14,13 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_pst.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "attention.hip", "capi.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "attention.hip", "capi.hip"]
 OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
-         "-Wno-unused-function", "-Wno-unknown-attributes",
-         # next-round kernel features that are compile-time gated out of the product build until measured on hardware
-         # (DESIGN.md section 9): their LOGIC is exercised here
-         "-DI2I_GEMM_GNPART=1", "-DI2I_PST_CONV=1"]
+         "-Wno-unused-function", "-Wno-unknown-attributes"]
 
 
 def _stale(out, deps):
@@ -42,8 +39,7 @@ def _cc(src_path, obj, lang_cxx, extra=()):
 
 
 def build(tag=None, extra=()):
-    """tag/extra: a second emulator library with additional defines (the LOGIC of the experiment build's source variants,
-    e.g. tag="next", extra=["-DI2I_GLDS_ASM=1"]: its asm statements are compiled out under I2I_EMU, the C++ around them is not)."""
+    """tag/extra: a second emulator library with additional defines (the LOGIC of an experiment build's source variants)."""
     bdir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
     out = OUT if not tag else os.path.join(bdir, "libi2i_turbo_emu_%s.so" % tag)
     os.makedirs(bdir, exist_ok=True)

@@ -2,8 +2,8 @@
 
     python tests/fuzz_emu.py <seed> <iterations>
 
-Random shapes for the persistent halo conv (tiles 43 / 44), the LDS-DMA igemm (one tile per workgroup and persistent stream, plain
-and gathered) under randomly chosen schedules of tests/emu (I2I_EMU_ASYNC, I2I_EMU_ORDER) and workgroup counts
+Random shapes for the halo conv (tiles 12 / 13 / 17 / 34) and the LDS-DMA igemm (one tile per workgroup and persistent stream,
+plain and gathered) under randomly chosen schedules of tests/emu (I2I_EMU_ASYNC, I2I_EMU_ORDER) and workgroup counts
 (I2I_PERSIST_WGS).  Prints every failing configuration; 160 configurations (seeds 1-4 x 40) passed when this was written."""
 import os, sys, random
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,13 +20,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 24):
     if o is None: os.environ.pop("I2I_EMU_ORDER",None)
     else: os.environ["I2I_EMU_ORDER"]=str(o)
     os.environ["I2I_PERSIST_WGS"]=str(rnd.choice([1,2,3,5,7]))
-    kind=rnd.choice(["pst43","pst44","gemm","gemm_gather"])
+    kind=rnd.choice(["halo","gemm","gemm_gather"])
     dt=rnd.choice([torch.bfloat16, torch.float16, torch.float32])
     try:
-        if kind.startswith("pst"):
+        if kind=="halo":
             cin=rnd.choice([64,128,192]) if dt!=torch.float32 else rnd.choice([32,64,96])
             kw=dict(n=rnd.choice([1,2,3]), cin=cin, cout=rnd.choice([64,72,128,200,256,328]), h=rnd.choice([8,9,16,20,24]), w=rnd.choice([16,17,32,40]),
-                    gn=rnd.choice([True,False]), res=rnd.choice([True,False]), tile=43 if kind=="pst43" else 44)
+                    gn=rnd.choice([True,False]), res=rnd.choice([True,False]), tile=rnd.choice([12,13,17,34]))
             if kw["gn"]: kw["act"]=1
             oc.check_conv(lib,"cpu",dt,**kw)
         elif kind=="gemm":

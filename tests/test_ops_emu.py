@@ -270,22 +270,6 @@ def test_dma_igemm_epilogue_groupnorm_partials(emu_lib, wgs, monkeypatch):
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=32, w=32, groups=8, tile=20, stride=2)          # stride-2 gather
 
 
-@pytest.mark.parametrize("cfg,wgs", [(43, 1), (43, 3), (47, 2), (43, 0), (44, 1), (44, 2)])
-def test_persistent_halo_conv(emu_lib, cfg, wgs, monkeypatch):
-    """Next-round kernel (conv3x3_pst.hip, compiled into the emulator build only): the halo conv as a persistent stream --
-    the following slab's halo / weights cross tile borders, the epilogue runs between tiles.  One, two and three slabs per
-    tile, ragged planes, two channel tiles (weight rows change at a tile border), GN + SiLU prologue, residual, several
-    images, 1 / 2 / 3 workgroups (and one tile per workgroup: wgs = 0)."""
-    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=72, h=20, w=40, gn=True, act=1, res=True, tile=cfg)        # 1 slab
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=cfg)                # 2 slabs, 2 n-tiles
-    oc.check_conv(emu_lib, "cpu", torch.float32, n=2, cin=96, cout=64, h=16, w=32, res=True, alpha=0.5, tile=cfg)              # f32: 3 slabs of 32
-    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cin2=64, cout=40, h=9, w=23, gn=True, act=1, tile=cfg)           # concat sources
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=64, h=8, w=16, ups=1, tile=cfg)                           # upsample index map
-    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=cfg)                # epilogue partial sums
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=32, res=True, tile=cfg)                       # exact tiles (counted stores)
-
-
 def test_gn_finalize_many_parts(emu_lib):
     """Finalize with hundreds / thousands of parts per image (what 512x512 conv epilogues hand over): the launcher
     switches to 2 and then 1 group per block."""

@@ -43,20 +43,6 @@ def test_attention_waits(async_lib):
     oc.check_attention(async_lib, "cpu", torch.float16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)    # wide head, double buffer
 
 
-@pytest.mark.parametrize("wgs", [1, 3])
-def test_persistent_halo_conv_waits(async_lib, wgs, monkeypatch):
-    monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
-    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=72, h=20, w=40, gn=True, act=1, res=True, tile=43)
-    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)
-    oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=20, w=24, groups=8, tile=43)
-    # exact tiles everywhere: the epilogue stores are COUNTED in the first two waits of the next tile (1 and 2 slabs per tile)
-    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=32, res=True, tile=43)
-    oc.check_conv(async_lib, "cpu", torch.float16, n=1, cin=128, cout=256, h=24, w=32, gn=True, act=1, tile=43)
-    # the 8-wave 8x16x256 form (tile 44): exact and ragged channel tiles
-    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=32, res=True, tile=44)
-    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=328, h=20, w=24, gn=True, act=1, tile=44)
-
-
 def test_model_is_sensitive_to_one_operation(async_lib, monkeypatch):
     """Self-test of the model: every wait one operation too generous (I2I_EMU_WAIT_BIAS=1) must break the kernels."""
     monkeypatch.setenv("I2I_EMU_WAIT_BIAS", "1")
@@ -85,21 +71,6 @@ def test_whole_forward_under_the_async_model(async_lib):
     assert (out.float() - ref).abs().max().item() < 0.25
 
 
-# ---- the experiment build's source variants under both memory models ----
-@pytest.mark.parametrize("async_model", ["0", "1"])
-def test_experiment_build_variants(emu_lib_next, async_model, monkeypatch):
-    lib = emu_lib_next
-    monkeypatch.setenv("I2I_EMU_ASYNC", async_model)
-    oc.check_attention(lib, "cpu", torch.bfloat16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)       # one K base ^ (j << 6), read-ahead 2
-    oc.check_attention(lib, "cpu", torch.float16, batch=2, heads=1, d=512, tq=130, tk=64)
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=64, cout=72, h=20, w=24, gn=True, act=1, res=True, tile=13)   # pitches pinned per source
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=12, w=20, ups=1, subpix=True)
-    monkeypatch.setenv("I2I_PERSIST_WGS", "2")
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=25)            # epilogue behind opaque lane ids
-    oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)                   # persistent halo conv
-
-
 # ---- barriers: run-ahead wave scheduling (I2I_EMU_ORDER): each wave runs a whole barrier interval ahead of the next one ----
 @pytest.mark.parametrize("order", ["0", "1", "7"])
 def test_barriers_under_wave_skew(emu_lib, order, monkeypatch):
@@ -120,8 +91,6 @@ def test_barriers_under_wave_skew(emu_lib, order, monkeypatch):
     oc.check_conv_gn_part(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=20, ks=1)
     oc.check_attention(lib, "cpu", torch.bfloat16, batch=1, heads=2, tq=130, tk=325, spike=True)
     oc.check_attention(lib, "cpu", torch.float16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=1, cin=128, cout=200, h=24, w=24, gn=True, act=1, tile=43)
-    oc.check_conv(lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=32, res=True, tile=44)
     oc.check_gn_stats(lib, "cpu", torch.bfloat16, c0=128, groups=32, h=40, w=32, nparts=1100, n=1)
     oc.check_layernorm(lib, "cpu", torch.bfloat16)
     oc.check_softmax(lib, "cpu", torch.bfloat16)

@@ -138,32 +138,10 @@ def test_subpixel_upsample_conv(gpu_lib, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wgs", ["", "0", "37"])
-def test_persistent_halo_conv(gpu_lib, wgs, monkeypatch):
-    """conv3x3_pst.hip (I2I_PST_CONV builds; skipped on a library without it): tile 43 on the real DMA path, resident-count
-    workgroups, one tile per workgroup, and an odd workgroup count (uneven tile shares); 2 and 8 slabs, GN prologue, residual."""
-    from img2img_turbo_amd._capi import I2IError
-    if wgs:
-        monkeypatch.setenv("I2I_PERSIST_WGS", wgs)
-    try:
-        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=128, w=128, gn=True, act=1, res=True, tile=43)
-    except I2IError as e:
-        if "unknown tile config" in str(e):
-            pytest.skip("this build of the library has no persistent halo conv (compile-time gated feature)")
-        raise
-    for rep in range(2):
-        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=4, cin=128, cout=200, h=96, w=80, gn=True, act=1, tile=43, seed=rep)
-        oc.check_conv(gpu_lib, "cuda", torch.float16, n=2, cin=512, cout=256, h=64, w=64, gn=True, act=1, res=True, tile=43, seed=rep)
-    oc.check_conv(gpu_lib, "cuda", torch.float32, n=2, cin=64, cout=128, h=40, w=52, tile=43)
-    oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=4, cin=256, cout=256, h=128, w=128, gn=True, act=1, res=True, tile=44)   # 8x16x256, 8 waves
-    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=64, w=64, groups=32, tile=43)
-
-
-@pytest.mark.gpu
 def test_dma_igemm_epilogue_groupnorm_partials(gpu_lib):
-    """GroupNorm partial sums from the LDS-DMA igemm epilogue (I2I_GEMM_GNPART builds; skipped on a library without it):
-    VAE skip-conv / conv_in / downsampler shapes, persistent stream included."""
-    kw = dict(skip_if_declined=True, tile=20)
+    """GroupNorm partial sums from the LDS-DMA igemm epilogue: VAE skip-conv / conv_in / downsampler shapes, persistent
+    stream included."""
+    kw = dict(tile=20)
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=256, w=256, groups=32, ks=1, **kw)           # persistent, 2 n-tiles
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=128, w=128, groups=32, stride=2, res=False, **kw)
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=4, cin=512, cout=512, h=32, w=32, groups=32, ks=1, **kw)
