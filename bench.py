@@ -156,7 +156,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--split", type=int, default=1, help="run the batch as this many sub-batch programs in parallel branches of the hipGraph")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
     a = ap.parse_args()
     global PER_OP_PATH
@@ -192,11 +191,11 @@ def main():
     # random init of the exact architecture (no checkpoints offline); every rank builds the same weights, its own images
     if a.model == "cyclegan":
         weights = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
-        model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype, split_batch=a.split)
+        model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype)
         kind, cfg = "photo", 3
     else:
         weights = make_pix2pix_weights(ua, va, seed=1234 + (4 if a.stochastic else 2), sketch=a.stochastic)
-        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype, split_batch=a.split)
+        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype)
         kind, cfg = ("sketch", 4) if a.stochastic else ("canny", 2)
     x, cap, eps, noise = synth_inputs(kind, B, a.size, ua.cross_attention_dim, va.latent_channels, 1234 + cfg + 1000 * rank)
     if a.model == "cyclegan":
@@ -235,7 +234,7 @@ def main():
            "dtype": a.dtype, "data": "synthetic (random-init weights of the SD-Turbo architecture + LoRA, seeded %s inputs)" % kind,
            "config": {"workload": "%s %s bs=%d/GPU %dx%d, hipGraph replay" % (name, a.dtype, B, a.size, a.size),
                       "global_batch": total, "parallelism": "dp%d (batch shards, replicated weights, RCCL gather of outputs)" % world,
-                      "arch": a.arch, "kernel_library": os.path.basename(model.lib.path), "graph_branches": a.split},
+                      "arch": a.arch, "kernel_library": os.path.basename(model.lib.path)},
            "baseline_note": "vs_baseline = value / 9.09 img/s (0.11 s per 512x512 image on A100, reference README.md:17)"}
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":

@@ -108,7 +108,7 @@ _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply"
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
            "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_run", "i2i_run_timed",
-           "i2i_graph_create", "i2i_graph_create_multi", "i2i_graph_launch", "i2i_graph_destroy"]
+           "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
 
 
 class I2IError(RuntimeError):
@@ -168,7 +168,6 @@ class Library:
         L.i2i_run.argtypes = [vp, C.c_int, vp]
         L.i2i_run_timed.argtypes = [vp, C.c_int, vp, vp]
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
-        L.i2i_graph_create_multi.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
         if L.i2i_abi_version() != 3:
@@ -197,14 +196,6 @@ class Library:
     def graph_create(self, prog):
         g = vp()
         self.check(self.lib.i2i_graph_create(C.addressof(prog.array), prog.n, C.byref(g)))
-        return g
-
-    def graph_create_multi(self, progs):
-        """One hipGraph whose parallel branches are the given independent programs."""
-        ptrs = (vp * len(progs))(*[C.addressof(p.array) for p in progs])
-        ns = (C.c_int * len(progs))(*[p.n for p in progs])
-        g = vp()
-        self.check(self.lib.i2i_graph_create_multi(ptrs, ns, len(progs), C.byref(g)))
         return g
 
     def graph_launch(self, g, stream=0):

@@ -649,9 +649,9 @@ void halo_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     switch (cfg) {
         case 11: case 19: *th = 16; *bn = 128; *wtn = 64; break;
         case 12: case 18: case 32: *th = 16; *bn = 128; *wtn = 64; break;
-        case 13: case 17: case 31: case 33: case 43: case 47: *th = 8; *bn = 128; *wtn = 64; break;
+        case 13: case 17: case 31: case 33: *th = 8; *bn = 128; *wtn = 64; break;
         case 14: *th = 16; *bn = 64; *wtn = 32; break;
-        case 34: case 44: *th = 8; *bn = 256; *wtn = 64; break;
+        case 34: *th = 8; *bn = 256; *wtn = 64; break;
         case 15: *th = 8; *bn = 64; *wtn = 32; break;
         default: *th = 8; *bn = 16; *wtn = 16; break;
     }

@@ -56,42 +56,6 @@ extern "C" int i2i_graph_create(const i2i_op* ops, int n_ops, void** graph_out) 
     return I2I_OK;
 }
 
-extern "C" int i2i_graph_create_multi(const i2i_op* const* progs, const int* n_ops, int n_progs, void** graph_out) {
-    if (!progs || !n_ops || !graph_out || n_progs < 1 || n_progs > 8) return i2i::fail(I2I_ERR_BAD_ARG, "graph_create_multi: bad arguments");
-    if (n_progs == 1) return i2i_graph_create(progs[0], n_ops[0], graph_out);
-    // fork / join by events inside the capture: the side streams join the capture through hipStreamWaitEvent on an event recorded
-    // in the origin stream, and are joined back the same way before hipStreamEndCapture
-    hipStream_t cap;
-    std::vector<hipStream_t> side((size_t)n_progs - 1);
-    std::vector<hipEvent_t> ev((size_t)n_progs);
-    I2I_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    for (auto& s : side) I2I_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    for (auto& e : ev) I2I_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    Graph* g = new Graph();
-    int rc = I2I_OK;
-    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) e = hipEventRecord(ev[0], cap);
-    for (int k = 1; k < n_progs && e == hipSuccess; ++k) e = hipStreamWaitEvent(side[k - 1], ev[0], 0);
-    for (int k = 0; k < n_progs && e == hipSuccess && rc == I2I_OK; ++k) rc = i2i_run(progs[k], n_ops[k], k == 0 ? (void*)cap : (void*)side[k - 1]);
-    for (int k = 1; k < n_progs && e == hipSuccess; ++k) {
-        e = hipEventRecord(ev[k], side[k - 1]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(cap, ev[k], 0);
-    }
-    hipError_t e2 = hipStreamEndCapture(cap, &g->graph);
-    if (e == hipSuccess) e = e2;
-    if (e == hipSuccess && rc == I2I_OK) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-    for (auto& s : side) (void)hipStreamDestroy(s);
-    for (auto& x : ev) (void)hipEventDestroy(x);
-    (void)hipStreamDestroy(cap);
-    if (rc != I2I_OK || e != hipSuccess) {
-        if (g->graph) (void)hipGraphDestroy(g->graph);
-        delete g;
-        return rc != I2I_OK ? rc : i2i::fail(I2I_ERR_RUNTIME, "graph_create_multi: %s", hipGetErrorString(e));
-    }
-    *graph_out = g;
-    return I2I_OK;
-}
-
 extern "C" int i2i_graph_launch(void* graph, void* stream) {
     if (!graph) return i2i::fail(I2I_ERR_BAD_ARG, "graph_launch: null graph");
     I2I_HIP(hipGraphLaunch(((Graph*)graph)->exec, (hipStream_t)stream));

@@ -19,7 +19,7 @@ import torch
 
 from . import _capi
 from .model import make_1step_sched
-from .plan import ForwardPlan, SplitPlan
+from .plan import ForwardPlan
 from .packer import Packer
 from .weights import GeneratorWeights, from_pix2pix_checkpoint, load_checkpoint_file, load_sd_turbo_base
 
@@ -65,7 +65,7 @@ class TurboGeneratorBase(torch.nn.Module):
     MAX_PLANS = 8          # distinct (batch, size, mode) programs kept alive; each owns an activation pool + a hipGraph
 
     def __init__(self, weights: GeneratorWeights, device="cuda", dtype=torch.float32, lib=None,
-                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None, split_batch=1):
+                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None):
         super().__init__()
         self.weights = weights
         self.device_ = torch.device(device)
@@ -80,7 +80,6 @@ class TurboGeneratorBase(torch.nn.Module):
         self.timesteps = self.sched.timesteps
         self.use_graph = use_graph and self.lib.backend == "gfx950"
         self.fuse_gn, self.flash = fuse_gn, flash
-        self.split_batch = split_batch    # >1: batches of >= 2*split_batch images run as that many parallel graph branches (plan.SplitPlan)
         self.plan_options = dict(plan_options or {})   # extra ForwardPlan switches (tests / ablations): halo_min_tiles, subpix, ...
         self._plans = collections.OrderedDict()
         self._packers = {}
@@ -157,14 +156,10 @@ class TurboGeneratorBase(torch.nn.Module):
             opts = dict(self.plan_options)
             if u8_io is not None:
                 opts["u8_io"] = u8_io
-            split = opts.pop("split", self.split_batch)
-            kw = dict(stochastic=stochastic, r=self._r, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
-                      flash=self.flash, packers=self._get_packers(direction), **opts)
             with self._on_device():
-                if split > 1 and B >= 2 * split:       # sub-batch programs as parallel graph branches (run back to back without a graph)
-                    self._plans[key] = SplitPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, parts=split, **kw)
-                else:
-                    self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, **kw)
+                self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
+                                               r=self._r, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
+                                               flash=self.flash, packers=self._get_packers(direction), **opts)
             while len(self._plans) > self.MAX_PLANS:      # LRU: the evicted plan's graph and activation pool are released
                 _, old = self._plans.popitem(last=False)
                 old.release()

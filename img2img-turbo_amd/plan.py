@@ -73,8 +73,7 @@ class ForwardPlan:
     of the plan: it lives in the packers' device scalars (Packer.set_scale), so one plan (and its hipGraph) serves every r."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True,
-                 boundary=None):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         # H, W multiples of 8 suffice (src/inference_paired.py:38-41): latent sizes that are not multiples of 8 make the
         # UNet levels odd (70 -> 35 -> 18 -> 9), handled like diffusers' forward_upsample_size path (explicit sizes).
@@ -115,16 +114,13 @@ class ForwardPlan:
         # (row f1: F.to_tensor / Normalize / x*0.5+0.5 / ToPILImage of the callers run inside the boundary kernels)
         self.u8_io = u8_io
         self.ctx_batch = ctx_batch
-        if boundary is not None:      # slices of a SplitPlan's full-batch boundary tensors
-            self.x_in, self.eps, self.noise, self.ctx, self.out = (boundary[k] for k in ("x_in", "eps", "noise", "ctx", "out"))
-        else:
-            self.x_in = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
-                         torch.zeros(B, 3, H, W, dtype=torch.float32, device=device))
-            self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
-            self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
-            self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=dtype, device=device)
-            self.out = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
-                        torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device))
+        self.x_in = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
+                     torch.zeros(B, 3, H, W, dtype=torch.float32, device=device))
+        self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
+        self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
+        self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=dtype, device=device)
+        self.out = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
+                    torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device))
         self._build()
         self._finish_gn_scratch()
         self.prog.freeze()
@@ -633,94 +629,3 @@ class ForwardPlan:
         self.pool.free_lists.clear()
         self._keep.clear()
 
-
-class _ProgView:
-    """Concatenated op list of several programs (reporting only: bench.py's per-op table)."""
-
-    def __init__(self, progs):
-        self.ops = [o for p in progs for o in p.ops]
-        self.n = sum(p.n for p in progs)
-
-
-class SplitPlan:
-    """One forward of B images as ``parts`` INDEPENDENT sub-batch programs (images never interact: per-sample norms and attention)
-    captured as parallel branches of ONE hipGraph (i2i_graph_create_multi).  The big convolutions fill the chip either way; what
-    overlaps are the many small launches of the UNet levels (grids of a few hundred workgroups), the tails of every launch and the
-    launch gaps of one branch with the kernels of the other.  Boundary tensors are full-batch; each sub-plan works on a contiguous
-    slice of them, weights (packers) are shared."""
-
-    def __init__(self, lib, weights, B, H, W, dtype, device, parts=2, **kw):
-        assert 2 <= parts <= B
-        self.lib, self.B, self.H, self.W, self.dtype, self.device = lib, B, H, W, dtype, device
-        stochastic, u8_io, ctx_batch = kw.get("stochastic", False), kw.get("u8_io"), kw.get("ctx_batch", 1)
-        ua, va = weights.unet_arch, weights.vae_arch
-        lat, h8, w8 = va.latent_channels, H // 8, W // 8
-        out_dtype = kw.get("out_dtype") or dtype
-        self.u8_io, self.ctx_batch, self.stochastic = u8_io, ctx_batch, stochastic
-        self.x_in = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
-                     torch.zeros(B, 3, H, W, dtype=torch.float32, device=device))
-        self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
-        self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
-        self.ctx = torch.zeros(ctx_batch, 77, ua.cross_attention_dim, dtype=dtype, device=device)
-        self.out = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
-                    torch.zeros(B, 3, H, W, dtype=out_dtype, device=device))
-        base, rem = divmod(B, parts)
-        self.parts, lo = [], 0
-        for k in range(parts):
-            n = base + (1 if k < rem else 0)
-            sl = slice(lo, lo + n)
-            bnd = dict(x_in=self.x_in[sl], eps=self.eps[sl], noise=self.noise[sl] if stochastic else None,
-                       ctx=self.ctx[sl] if ctx_batch == B else self.ctx, out=self.out[sl])
-            sub_kw = dict(kw, ctx_batch=(n if ctx_batch == B else ctx_batch))
-            self.parts.append(ForwardPlan(lib, weights, n, H, W, dtype, device, boundary=bnd, **sub_kw))
-            lo += n
-        self.pool = self.parts[0].pool
-        self.graph = None
-
-    # reporting views used by bench.py (concatenation over the branches)
-    @property
-    def prog(self):
-        return _ProgView([p.prog for p in self.parts])
-
-    @property
-    def op_kernel(self):
-        return [k for p in self.parts for k in p.op_kernel]
-
-    @property
-    def op_flops(self):
-        return [f for p in self.parts for f in p.op_flops]
-
-    @property
-    def halo_flops_real(self):
-        return sum(getattr(p, "halo_flops_real", 0) for p in self.parts)
-
-    @property
-    def flops(self):
-        return sum(p.flops for p in self.parts)
-
-    def stream(self):
-        return self.parts[0].stream()
-
-    def run(self):
-        for p in self.parts:
-            p.run()
-
-    def run_timed(self):
-        return [t for p in self.parts for t in p.run_timed()]
-
-    def capture(self):
-        if self.graph is None:
-            with self.parts[0]._on_device():
-                self.graph = self.lib.graph_create_multi([p.prog for p in self.parts])
-        return self.graph
-
-    def replay(self):
-        with self.parts[0]._on_device():
-            self.lib.graph_launch(self.capture(), self.stream())
-
-    def release(self):
-        if self.graph is not None:
-            self.lib.graph_destroy(self.graph)
-            self.graph = None
-        for p in self.parts:
-            p.release()

@@ -245,10 +245,6 @@ int i2i_run(const i2i_op* ops, int n_ops, void* stream);
 int i2i_run_timed(const i2i_op* ops, int n_ops, void* stream, float* ms);
 /* Capture the program into a hipGraph (launch-bound bs=1 path) and replay it. */
 int i2i_graph_create(const i2i_op* ops, int n_ops, void** graph_out);
-/* Same for several INDEPENDENT programs (disjoint buffers, e.g. the two half-batches of one forward): captured as parallel
- * branches of one hipGraph, so the short launches and the tails of one branch overlap with the other's kernels.  Each program
- * still runs in order inside its branch. */
-int i2i_graph_create_multi(const i2i_op* const* progs, const int* n_ops, int n_progs, void** graph_out);
 int i2i_graph_launch(void* graph, void* stream);
 int i2i_graph_destroy(void* graph);
 

@@ -14,11 +14,5 @@ namespace { struct G { std::vector<i2i_op> ops; }; }
 extern "C" int i2i_graph_create(const i2i_op* ops, int n_ops, void** out) {
     G* g = new G(); g->ops.assign(ops, ops + n_ops); *out = g; return 0;
 }
-extern "C" int i2i_graph_create_multi(const i2i_op* const* progs, const int* n_ops, int n_progs, void** out) {
-    G* g = new G();
-    for (int k = 0; k < n_progs; ++k) g->ops.insert(g->ops.end(), progs[k], progs[k] + n_ops[k]);      // branches run back to back
-    *out = g;
-    return 0;
-}
 extern "C" int i2i_graph_launch(void* g, void* stream) { G* gg = (G*)g; return i2i_run(gg->ops.data(), (int)gg->ops.size(), stream); }
 extern "C" int i2i_graph_destroy(void* g) { delete (G*)g; return 0; }

@@ -112,22 +112,3 @@ def test_pix2pix_odd_latent_size_fp32(emu_lib):
     assert out.shape == ref.shape
     assert (out - ref).abs().max().item() < 1e-3
 
-
-@pytest.mark.slow
-def test_split_plan_matches_single_plan(emu_lib):
-    """plan.SplitPlan (sub-batch programs over slices of the full-batch boundary tensors; on the GPU: parallel branches of one
-    hipGraph) must give exactly what the single program gives -- ragged split 3 = 2 + 1, per-image caption embeddings."""
-    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
-    x, cap, eps, _ = make_inputs("canny", 3, 64, 64, TINY_UNET.cross_attention_dim)
-    cap3 = torch.cat([cap, cap * 0.5, -cap], 0)
-    one = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
-    two = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib, plan_options=dict(split=1), split_batch=1)
-    two.plan_options["split"] = 2
-    a = one(x, caption_enc=cap3, eps=eps)
-    from img2img_turbo_amd.plan import SplitPlan
-    two.MAX_PLANS = 4
-    # B = 3 < 2 * split: force the split path through the plan option on a batch of 4 instead
-    x4, eps4, cap4 = torch.cat([x, x[:1]]), torch.cat([eps, eps[:1]]), torch.cat([cap3, cap3[:1]])
-    b = two(x4, caption_enc=cap4, eps=eps4)
-    assert isinstance(next(iter(two._plans.values())), SplitPlan)
-    assert torch.equal(a, b[:3]) and torch.equal(b[0], b[3])

@@ -263,18 +263,3 @@ def test_plan_cache_is_bounded(gpu_lib):
     assert again.shape == first.shape
     _free(model)
 
-
-def test_split_plan_parallel_graph_branches(gpu_lib):
-    """plan.SplitPlan on the GPU: the two half-batch programs run as parallel branches of ONE hipGraph (i2i_graph_create_multi)
-    and must reproduce the single-program output bit for bit, replay after replay (no cross-branch buffer sharing)."""
-    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
-    x, cap, eps, _ = make_inputs("canny", 6, 128, 64, TINY_UNET.cross_attention_dim)
-    one = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
-    two = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16, split_batch=3)
-    a = one(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
-    from img2img_turbo_amd.plan import SplitPlan
-    for _ in range(3):
-        b = two(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
-        assert torch.equal(a, b)
-    assert isinstance(next(iter(two._plans.values())), SplitPlan)
-    _free(one, two)
