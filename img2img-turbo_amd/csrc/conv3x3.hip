@@ -640,6 +640,7 @@ int halo_cfg(const i2i_igemm_params& p) {
         else if (p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64)) cfg = tall ? 14 : 15;
         else if (p.ups && tall && p.c0 + p.c1 >= 512) cfg = 18;   // measured (profiles/r1_conv_tiles_bench_ops.log)
         else if (p.N == 256 && p.c0 + p.c1 == 256 && p.ho * p.wo >= 128 * 128) cfg = 34;   // +6 % (profiles/r1_conv_bn256_bench_ops.log)
+        else if (p.c0 + p.c1 <= 128 && tall && p.ho * p.wo >= 256 * 256) cfg = 12;   // 2-slab tiles: +5..15 % over 13/17 (profiles/r2_conv_tiles_128ch_bench_ops.log)
         else cfg = (p.c0 + p.c1 <= 256) ? 17 : 13;
     }
     return cfg;

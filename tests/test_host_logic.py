@@ -137,13 +137,25 @@ full = torch.arange(total * 3 * 2 * 2, dtype=torch.float32).reshape(total, 3, 2,
 mine = dp.shard(full, rank, world) * 2.0      # "forward" of this rank's images
 out = dp.gather_images(mine, total, dst=0)
 m = dp.max_over_ranks(float(rank + 1), "cpu")
+# persistent gather (what bench.py's timed loop and a serving loop use): buffers allocated once, called every step
+even = torch.zeros(2, 3, 2, 2)
+g = dp.OutputGather(even, 4, dst=0)
+slabs = []
+for step in range(3):
+    even.fill_(10.0 * step + rank)          # the plan's static output buffer is rewritten in place every step
+    slab = g()
+    if rank == 0:
+        slabs.append(slab.data_ptr())
+        imgs = g.images()
+        assert imgs.shape == (4, 3, 2, 2) and torch.all(imgs[:2] == 10.0 * step) and torch.all(imgs[2:] == 10.0 * step + 1), imgs
 dp.barrier()
 if rank == 0:
     assert torch.equal(out, full * 2.0), out
     assert m == float(world)
+    assert len(set(slabs)) == 1, "the gather must reuse its buffers"
     print("DP_OK")
 else:
-    assert out is None
+    assert out is None and g.images() is None
 """
 
 
@@ -288,3 +300,34 @@ def test_pretrained_name_constructor_with_local_snapshot(tmp_path, emu_lib, monk
     monkeypatch.delenv("I2I_SD_TURBO_DIR")
     with pytest.raises(ValueError):
         Pix2Pix_Turbo(pretrained_name="edge_to_image", ckpt_folder=str(ck), device="cpu", lib=emu_lib)
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment must become the launcher (one rank per GPU on 127.0.0.1) instead
+    of asserting; under torch.distributed.run (WORLD_SIZE set) it must NOT re-launch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    class Launched(Exception):
+        pass
+
+    def fake_execv(exe, argv):
+        calls.append(argv)
+        raise Launched()
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(Launched):
+        bench.main()
+    argv = calls[0]
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in argv and argv[argv.index("--nproc-per-node") + 1] == "4"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # inside a torchrun rank whose WORLD_SIZE disagrees with --gpus: a clear error, no second launch
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises((SystemExit, AssertionError, RuntimeError, ValueError)):
+        bench.main()
+    assert len(calls) == 1
