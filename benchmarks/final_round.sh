@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round evidence set, from the repo root on the GPU box:  benchmarks/final_round.sh r2   (writes gpurun_out/<tag>_*)
+#   1. the bench line of the headline configuration (cfg 2) with the CPU oracle beside it and the parity of image 0
+#   2. rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / total / average)
+#   3. HBM traffic of the halo conv launches: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), corrected per
+#      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3_halo.json keyed on the kernel-source hash
+#   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
+TAG=${1:-r2}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
+CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
+cp $O/${TAG}_trace/*/trace_kernel_stats.csv $O/${TAG}_bench_bs8_kernel_stats.csv 2>/dev/null || cp $O/${TAG}_trace/trace_kernel_stats.csv $O/${TAG}_bench_bs8_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
+F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/${TAG}_write -name "*counter_collection.csv" | head -1)
+python tools/pmc_traffic.py $F $W conv3x3_halo_kernel --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
+    --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3_halo.json
+cp $O/${TAG}_traffic_conv3x3_halo.json profiles/traffic_conv3x3_halo.json
+python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
+python bench.py --batch 1 --no-cpu-baseline > $O/${TAG}_bench_bs1.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --batch 32 --no-cpu-baseline --steps 20 > $O/${TAG}_bench_bs32.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --model cyclegan --batch 4 > $O/${TAG}_bench_cfg3_cyclegan_bs4.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --stochastic --gamma 0.4 --batch 16 > $O/${TAG}_bench_cfg4_stochastic_bs16.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --size 1024 --dtype f16 --batch 8 --steps 10 --no-cpu-baseline > $O/${TAG}_bench_cfg5_1024_f16_bs8.json 2>> $O/${TAG}_bench_bs8.err
+for f in $O/${TAG}_bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    r = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split("/")[-1], r["value"], "img/s", r["ms_per_step"], "ms/step", "frac", (r.get("roofline") or {}).get("frac"), "parity", r.get("parity_max_abs"), r.get("parity_psnr_db"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
+head -8 $O/${TAG}_bench_bs8_kernel_stats.csv | cut -c1-180
+cat $O/${TAG}_traffic_conv3x3_halo.json
