@@ -76,7 +76,8 @@ def main():
         gn = 0 if a.nogn else gn
         ss = torch.randn(B, cin, 2, device=dev) if gn else None
         for tile, sk in [(int(t), int(k)) for t in a.tiles.split(",") for k in a.splitk.split(",")]:
-            ws = torch.empty(sk * B * ho * wo * cout, device=dev) if sk > 1 else None
+            # trace builds reuse the split-K field of the halo conv as ablation bits: no split-K slab then
+            ws = torch.empty(sk * B * ho * wo * cout, device=dev) if (sk > 1 and not (a.lib and "trace" in a.lib)) else None
             if a.trace:
                 ws = torch.zeros(B * ho * wo * ((cout + 63) // 64) // 4, dtype=torch.int32, device=dev)   # >= workgroups * waves * 16
             prog = K.Program()

@@ -91,6 +91,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+#ifdef I2I_TRACE
+    // phase-stagger experiment: the two workgroups of a CU start together and run identical tiles, so their serial phases
+    // (prologue, slab hand-over, epilogue) coincide; delay one of each pair once at the start of the launch
+    if (blockIdx.x < 512) {
+        const int idx = blockIdx.x >> 3;
+        if ((I2I_ABL(64) && (idx & 1)) || (I2I_ABL(128) && (idx & 32))) { __builtin_amdgcn_s_sleep(96); }
+        if ((I2I_ABL(256) && (idx & 1)) || (I2I_ABL(512) && (idx & 32))) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+    }
+#endif
     // plane the tiles walk over: the output plane, or the SOURCE plane for the sub-pixel form
     const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;
     const int tiles_x = (pl_w + TW - 1) / TW, tiles_y = (pl_h + TH - 1) / TH;
