@@ -44,4 +44,6 @@ def gpu_lib():
     assert torch.cuda.is_available(), "gpu-marked test without a GPU"
     lib = _capi.default_library()
     assert lib.backend == "gfx950"
+    # the -m gpu suite certifies the PRODUCT library: an I2I_LIB override (measurement builds) must not ride along silently
+    assert os.path.realpath(lib.path) == os.path.realpath(_capi.DEFAULT_LIB), "I2I_LIB points the GPU tests at %s" % lib.path
     return lib
