@@ -78,7 +78,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
     // ablation switches of the trace build (p.splitk is otherwise unused by this kernel; results are WRONG with any bit set):
     // 1 no output stores, 2 no bias loads, 4 no weight DMA inside the step loop, 8 no MFMAs, 16 no halo loads inside the step loop
 #define I2I_ABL(bit) ((p.splitk & (bit)) != 0)
+#define I2I_SETPRIO(v) do { if (I2I_ABL(1024)) __builtin_amdgcn_s_setprio(v); } while (0)
 #else
+#define I2I_SETPRIO(v) do { } while (0)
 #define I2I_TR(k) do { } while (0)
 #define I2I_ABL(bit) false
 #endif
@@ -429,9 +431,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
             wait_vmcnt<(RING == 3) ? DMA_OPS : 0>();                        // my halo loads have landed (the newer DMA batch stays in flight)
 #pragma unroll
             for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+            I2I_SETPRIO(0);
             lds_barrier();
             halo_store_all();
             lds_barrier();
+            I2I_SETPRIO(1);
             I2I_TR(5);
         }
     };
@@ -440,12 +444,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #pragma unroll
     for (int j = 0; j < FN; ++j) w0[j] = wf_read(0, 0, j);     // buffer 0 in both layouts
     I2I_TR(6);
+    I2I_SETPRIO(1);      // MFMA stream first: the co-resident workgroup's VALU phases (prologue / hand-over / epilogue) take the leftover slots
     for (int slab = 0; slab < nslab; ++slab) {
         const bool next_slab = slab + 1 < nslab;
         static_for<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, next_slab, tc); });
     }
     // The last slab issued its (unused) halo loads too: they must have landed before the epilogue may reuse their
     // destination registers -- hipcc does not know those registers have a write in flight.
+    I2I_SETPRIO(0);
     wait_vmcnt<0>();
 #pragma unroll
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3_halo_kernel(const i
 #endif
 #undef I2I_TR
 #undef I2I_ABL
+#undef I2I_SETPRIO
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int PD, int MINW, bool SUBPIX = false, bool DBH = false>
