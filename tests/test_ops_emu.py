@@ -315,3 +315,4 @@ def test_conv_explicit_upsample_size(emu_lib):
                        stride=1, pad=1, ups=1, N=cout, tile=10, up_size=(uh, uw))
     oc.run_op(emu_lib, opcode, p, torch.bfloat16, "cpu")
     assert oc.rel_err(out.float().permute(0, 3, 1, 2), ref) < oc.TOL[torch.bfloat16]
+
