@@ -15,6 +15,7 @@ F32, BF16, F16, U8 = 0, 1, 2, 3
 OP_IGEMM, OP_GN_STATS, OP_LAYERNORM, OP_SOFTMAX = 1, 2, 3, 4
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY, OP_EMBED = 5, 6, 7, 8, 9, 10, 11
 OP_LORA_MERGE = 12
+OP_RESIZE_U8 = 13
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -89,11 +90,16 @@ class LoraMergeParams(C.Structure):
     _fields_ = [("dst", vp), ("w0", vp), ("a", vp), ("b", vp), ("N", i32), ("K", i32), ("rank", i32), ("use_gamma", i32), ("rg", vp)]
 
 
+class ResizeU8Params(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n", i32), ("hin", i32), ("win", i32), ("c", i32), ("axis", i32), ("nout", i32), ("ksize", i32),
+                ("bounds", vp), ("coeffs", vp)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmParams), ("gn_stats", GnStatsParams), ("gn_apply", GnApplyParams),
                 ("layernorm", LayerNormParams), ("softmax", SoftmaxParams), ("attention", AttentionParams),
                 ("to_nhwc", NchwToNhwcParams), ("to_nchw", NhwcToNchwParams), ("embed", EmbedParams),
-                ("posterior", PosteriorParams), ("ddpm", DdpmParams), ("lora_merge", LoraMergeParams)]
+                ("posterior", PosteriorParams), ("ddpm", DdpmParams), ("lora_merge", LoraMergeParams), ("resize_u8", ResizeU8Params)]
 
 
 class Op(C.Structure):
@@ -103,11 +109,11 @@ class Op(C.Structure):
 _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply", OP_LAYERNORM: "layernorm",
              OP_SOFTMAX: "softmax", OP_ATTENTION: "attention", OP_NCHW_TO_NHWC: "to_nhwc",
              OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed",
-             OP_LORA_MERGE: "lora_merge"}
+             OP_LORA_MERGE: "lora_merge", OP_RESIZE_U8: "resize_u8"}
 
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
-           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_run", "i2i_run_timed",
+           "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
 
 
@@ -160,7 +166,7 @@ class Library:
         L.i2i_last_error.restype = C.c_char_p
         L.i2i_sizeof_op.restype = C.c_size_t
         for name in ("i2i_igemm", "i2i_gn_stats", "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention",
-                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge"):
+                     "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8"):
             getattr(L, name).argtypes = [vp, C.c_int, vp]
             getattr(L, name).restype = C.c_int
         L.i2i_igemm_gn_parts.argtypes = [vp, C.c_int, C.c_int]

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
 HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
 LIB = os.path.join(HERE, "libi2i_turbo.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -46,11 +46,24 @@ class CycleGAN_Turbo(TurboGeneratorBase):
         self.vae_enc._model = self.vae_dec._model = self.unet._model = self
 
     @torch.no_grad()
-    def forward_u8(self, images_u8, *args, **kw):
+    def forward_u8(self, images_u8, *args, resize=None, resize_back=False, **kw):
         """uint8 HWC in/out on the device: ``Normalize([0.5],[0.5])(to_tensor(img))`` (src/inference_unpaired.py:47) and
-        ``ToPILImage()(out*0.5+0.5)`` (:53) run inside the boundary kernels."""
+        ``ToPILImage()(out*0.5+0.5)`` (:53) run inside the boundary kernels.  ``resize=(width, height)`` applies the script's
+        ``transforms.Resize(..., LANCZOS)`` (:40-47, e.g. (512, 512) for "resize_512x512") before the generator and
+        ``resize_back=True`` its ``output_pil.resize((input width, input height), Image.LANCZOS)`` (:53) after it, both on the
+        device and bit-identical to Pillow (image_ops.lanczos_resize_u8)."""
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
-        return self.forward(images_u8, *args, _u8_io=(2.0, -1.0), **kw)
+        in_hw = images_u8.shape[1:3]
+        if resize is not None:
+            from .image_ops import lanczos_resize_u8
+            with self._on_device():
+                images_u8 = lanczos_resize_u8(images_u8, resize, self.lib)
+        out = self.forward(images_u8, *args, _u8_io=(2.0, -1.0), **kw)
+        if resize_back and tuple(out.shape[1:3]) != tuple(in_hw):
+            from .image_ops import lanczos_resize_u8
+            with self._on_device():
+                out = lanczos_resize_u8(out, (in_hw[1], in_hw[0]), self.lib)
+        return out
 
     @staticmethod
     @torch.no_grad()

@@ -1,0 +1,102 @@
+"""Device-side image pre/post-processing of the callers (row f1): LANCZOS resize of uint8 HWC image batches, bit-identical to
+Pillow, which the reference applies on the host before and after the generator:
+
+  src/inference_paired.py:38-41    input_image.resize((w - w % 8, h - h % 8), Image.LANCZOS)
+  src/inference_unpaired.py:40,53  transforms.Resize((512, 512), LANCZOS) ... output_pil.resize(input size, Image.LANCZOS)
+
+The tap windows and 22-bit fixed-point weights are computed here in double precision exactly as Pillow's
+``precompute_coeffs`` / ``normalize_coeffs_8bpc`` do (src/libImaging/Resample.c); the two integer passes run in
+csrc/resize.hip through ``i2i_resize_u8``.  Pure plumbing otherwise: no pixel arithmetic happens in Python.
+"""
+import ctypes as C
+import functools
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _sinc(x):
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x):
+    if -3.0 <= x < 3.0:
+        return _sinc(x) * _sinc(x / 3)
+    return 0.0
+
+
+@functools.lru_cache(maxsize=64)
+def lanczos_coeffs(in_size, out_size):
+    """Pillow's per-output-coordinate tap window and weights for one axis: (ksize, bounds int32 [out, 2], weights int32 [out, ksize])."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 3.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        ww = 0.0
+        for x in range(xmax):
+            w = _lanczos((x + xmin - center + 0.5) * ss)
+            kk[xx, x] = w
+            ww += w
+        if ww != 0.0:
+            for x in range(xmax):
+                kk[xx, x] /= ww
+        bounds[xx] = (xmin, xmax)
+    ik = np.where(kk < 0, (-0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64),
+                  (0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64)).astype(np.int32)
+    return ksize, bounds, ik
+
+
+_DEV_TABLES = {}
+
+
+def _tables(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    if key not in _DEV_TABLES:
+        ksize, b, k = lanczos_coeffs(in_size, out_size)
+        _DEV_TABLES[key] = (ksize, torch.from_numpy(b.copy()).to(device), torch.from_numpy(k.copy()).to(device))
+    return _DEV_TABLES[key]
+
+
+def lanczos_resize_u8(images, size, lib=None):
+    """images: uint8 [N, H, W, C] (C <= 4) on the device -> uint8 [N, size[1], size[0], C]; ``size`` = (width, height) as PIL takes it.
+    Bit-identical to ``Image.resize(size, Image.LANCZOS)`` per image.  Asynchronous on the current stream."""
+    assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] <= 4
+    lib = lib or _capi.default_library()
+    n, h, w, c = images.shape
+    ow, oh = int(size[0]), int(size[1])
+    cur = images.contiguous()
+    dev = cur.device
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+    for axis, n_in, n_out in ((1, w, ow), (0, h, oh)):          # Pillow's order: horizontal pass, then vertical pass
+        if n_in == n_out:
+            continue
+        ksize, bounds, coeffs = _tables(n_in, n_out, dev)
+        hin, win = cur.shape[1], cur.shape[2]
+        out = torch.empty((n, hin, n_out, c) if axis == 1 else (n, n_out, win, c), dtype=torch.uint8, device=dev)
+        p = _capi.ResizeU8Params()
+        p.src, p.dst, p.n, p.hin, p.win, p.c = cur.data_ptr(), out.data_ptr(), n, hin, win, c
+        p.axis, p.nout, p.ksize, p.bounds, p.coeffs = axis, n_out, ksize, bounds.data_ptr(), coeffs.data_ptr()
+        lib.check(lib.lib.i2i_resize_u8(C.addressof(p), 0, stream))
+        cur = out
+    return cur
+
+
+def resize_to_multiple_of_8(images, lib=None):
+    """src/inference_paired.py:38-41 on the device: LANCZOS resize to (w - w % 8, h - h % 8)."""
+    h, w = images.shape[1], images.shape[2]
+    return lanczos_resize_u8(images, (w - w % 8, h - h % 8), lib)

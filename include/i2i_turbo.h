@@ -50,7 +50,8 @@ typedef enum {
     I2I_OP_ATTENTION = 9,
     I2I_OP_GN_APPLY = 10,
     I2I_OP_EMBED = 11,
-    I2I_OP_LORA_MERGE = 12
+    I2I_OP_LORA_MERGE = 12,
+    I2I_OP_RESIZE_U8 = 13
 } i2i_opcode;
 
 /* ---------------------------------------------------------------------------------------------
@@ -197,6 +198,18 @@ typedef struct {
     const float* rg;
 } i2i_lora_merge_params;
 
+/* One separable pass of Pillow's LANCZOS resampling on uint8 HWC image batches [n][hin][win][c] (c <= 4), bit-identical to
+ * Image.resize(size, Image.LANCZOS) when the horizontal pass (axis = 1: win -> nout columns) is followed by the vertical pass
+ * (axis = 0: hin -> nout rows): the reference's host-side resizes (src/inference_paired.py:38-41, src/inference_unpaired.py:40,53).
+ * bounds[o] = (first tap, tap count), coeffs[o][ksize] = 22-bit fixed-point weights, both device int32 arrays computed on the
+ * host (image_ops.py restates Pillow's precompute_coeffs / normalize_coeffs_8bpc); out = clip8((2^21 + sum in*k) >> 22). */
+typedef struct {
+    const void* src; void* dst; int32_t n, hin, win, c;
+    int32_t axis;              /* 1 = horizontal pass (resample x), 0 = vertical pass (resample y) */
+    int32_t nout, ksize;       /* output extent along `axis`; weights per output coordinate */
+    const int32_t* bounds; const int32_t* coeffs;
+} i2i_resize_u8_params;
+
 typedef struct {
     int32_t opcode;    /* i2i_opcode */
     int32_t dtype;     /* i2i_dtype */
@@ -213,6 +226,7 @@ typedef struct {
         i2i_ddpm_params ddpm;
         i2i_embed_params embed;
         i2i_lora_merge_params lora_merge;
+        i2i_resize_u8_params resize_u8;
     } u;
 } i2i_op;
 
@@ -238,6 +252,7 @@ int i2i_posterior(const i2i_posterior_params* p, int dtype, void* stream);
 int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream);
 int i2i_embed(const i2i_embed_params* p, int dtype, void* stream);
 int i2i_lora_merge(const i2i_lora_merge_params* p, int dtype, void* stream);
+int i2i_resize_u8(const i2i_resize_u8_params* p, int dtype, void* stream);   /* dtype ignored (uint8 data) */
 
 /* ---- programs: a forward pass is a flat array of ops executed in order on one stream ---- */
 int i2i_run(const i2i_op* ops, int n_ops, void* stream);

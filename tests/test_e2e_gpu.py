@@ -263,3 +263,22 @@ def test_plan_cache_is_bounded(gpu_lib):
     assert again.shape == first.shape
     _free(model)
 
+
+
+def test_u8_pipeline_with_device_side_resize(gpu_lib):
+    """The whole paired-inference script on the device (src/inference_paired.py:38-72): uint8 image of any size -> LANCZOS resize
+    to a multiple of 8 (bit-identical to Pillow) -> to_tensor -> generator -> *0.5+0.5 -> uint8, against the same pipeline with
+    the resize done by Pillow on the host."""
+    import numpy as np
+    from PIL import Image
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (2, 77, 93, 3), dtype=np.uint8)
+    cap = torch.randn(1, 77, TINY_UNET.cross_attention_dim).cuda()
+    eps = torch.randn(2, 4, 9, 11).cuda()
+    out_dev = model.forward_u8(torch.from_numpy(img).cuda(), caption_enc=cap, eps=eps, resize="multiple_of_8")
+    host = np.stack([np.asarray(Image.fromarray(im, "RGB").resize((88, 72), Image.LANCZOS)) for im in img])
+    out_host = model.forward_u8(torch.from_numpy(host).cuda(), caption_enc=cap, eps=eps)
+    assert out_dev.shape == (2, 72, 88, 3) and torch.equal(out_dev, out_host)
+    _free(model)

@@ -316,3 +316,22 @@ def test_conv_explicit_upsample_size(emu_lib):
     oc.run_op(emu_lib, opcode, p, torch.bfloat16, "cpu")
     assert oc.rel_err(out.float().permute(0, 3, 1, 2), ref) < oc.TOL[torch.bfloat16]
 
+
+
+def test_lanczos_resize_u8_is_bit_identical_to_pillow(emu_lib):
+    """csrc/resize.hip through the C ABI vs Pillow itself (the implementation the reference's scripts call,
+    src/inference_paired.py:38-41, src/inference_unpaired.py:40,53): uint8 HWC batches, down- and up-scaling, one axis only."""
+    import numpy as np
+    from PIL import Image
+    from img2img_turbo_amd.image_ops import lanczos_resize_u8, resize_to_multiple_of_8
+    rng = np.random.default_rng(1)
+    for (n, h, w, oh, ow) in [(2, 37, 53, 32, 48), (1, 90, 160, 64, 64), (2, 40, 24, 72, 56), (1, 33, 64, 32, 64), (1, 64, 45, 64, 40)]:
+        a = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        a[:, : h // 3] = (a[:, : h // 3] > 127) * 255
+        got = lanczos_resize_u8(torch.from_numpy(a), (ow, oh), emu_lib).numpy()
+        for i in range(n):
+            ref = np.asarray(Image.fromarray(a[i], "RGB").resize((ow, oh), Image.LANCZOS))
+            assert np.array_equal(got[i], ref), (n, h, w, oh, ow)
+    a = rng.integers(0, 256, (1, 37, 53, 3), dtype=np.uint8)
+    got = resize_to_multiple_of_8(torch.from_numpy(a), emu_lib).numpy()
+    assert np.array_equal(got[0], np.asarray(Image.fromarray(a[0], "RGB").resize((48, 32), Image.LANCZOS)))

@@ -182,3 +182,29 @@ def test_softmax_row_kernel(gpu_lib, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_u8_boundary(gpu_lib, dtype):
     oc.check_u8_boundary(gpu_lib, "cuda", dtype, n=2, h=64, w=48)
+
+
+@pytest.mark.gpu
+def test_lanczos_resize_u8_is_bit_identical_to_pillow(gpu_lib):
+    """csrc/resize.hip on the GPU vs Pillow (src/inference_paired.py:38-41: to a multiple of 8; src/inference_unpaired.py:40,53:
+    1280x720 frames to 512x512 and back)."""
+    import time
+    import numpy as np
+    from PIL import Image
+    from img2img_turbo_amd.image_ops import lanczos_resize_u8
+    rng = np.random.default_rng(2)
+    for (n, h, w, oh, ow) in [(2, 561, 843, 560, 840), (2, 720, 1280, 512, 512), (2, 512, 512, 720, 1280), (3, 37, 53, 32, 48)]:
+        a = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        a[:, : h // 3] = (a[:, : h // 3] > 127) * 255
+        got = lanczos_resize_u8(torch.from_numpy(a).cuda(), (ow, oh), gpu_lib).cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], np.asarray(Image.fromarray(a[i], "RGB").resize((ow, oh), Image.LANCZOS))), (n, h, w, oh, ow)
+    x = torch.randint(0, 256, (32, 720, 1280, 3), dtype=torch.uint8, device="cuda")
+    lanczos_resize_u8(x, (512, 512), gpu_lib)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        y = lanczos_resize_u8(x, (512, 512), gpu_lib)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print("[resize] 32 x 1280x720 -> 512x512: %.3f ms, %.0f GB/s of input+output bytes" % (dt * 1e3, (x.numel() + y.numel()) / dt / 1e9))

@@ -185,3 +185,20 @@ def test_oracle_matches_reference_golden():
             mw = make_cyclegan_weights(TINY_UNET, TINY_VAE, rank_unet=16)
             out = cyclegan_forward(mw, rec["x"], rec["caption_enc"], rec["eps_enc"], direction=rec["direction"], eps_sched=rec["eps_sched"])
         assert (out - rec["out"]).abs().max().item() < 1e-4, f
+
+
+def test_lanczos_resize_oracle_is_pinned_against_pillow():
+    """oracle/resize.py vs the real implementation the reference calls (Pillow, installed): bit-identical for every size class the
+    reference produces -- to a multiple of 8 (src/inference_paired.py:38-41), 1280x720 driving frames to 512x512 and back
+    (src/inference_unpaired.py:40,53), upscaling, identity, extreme aspect."""
+    import numpy as np
+    from PIL import Image
+    from oracle.resize import lanczos_resize_u8
+    rng = np.random.default_rng(0)
+    for (h, w, oh, ow) in [(37, 53, 32, 48), (561, 843, 560, 840), (100, 60, 256, 256), (720, 1280, 512, 512), (64, 64, 64, 64),
+                           (17, 200, 8, 72), (512, 512, 720, 1280), (9, 9, 8, 8)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if h * w < 5000:
+            a[: h // 2] = (a[: h // 2] > 127) * 255          # hard edges: negative lobes and clipping at 0 / 255
+        ref = np.asarray(Image.fromarray(a, "RGB").resize((ow, oh), Image.LANCZOS))
+        assert np.array_equal(lanczos_resize_u8(a, ow, oh), ref), (h, w, oh, ow)
