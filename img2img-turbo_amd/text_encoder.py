@@ -93,6 +93,8 @@ class ClipTextEncoder(torch.nn.Module):
         super().__init__()
         self.lib = lib or K.default_library()
         self.device, self.dtype = torch.device(device), dtype
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if self.lib.backend == "gfx950" and self.device.type != "cuda":
             raise K.I2IError("the gfx950 kernel library needs a CUDA/HIP device, got %s" % device)
         self.arch = arch or arch_from_state_dict(state_dict)
@@ -125,16 +127,19 @@ class ClipTextEncoder(torch.nn.Module):
         """input_ids int64 [B, 77] -> (last_hidden_state [B, 77, hidden],) like ``CLIPTextModel(ids)``."""
         assert input_ids.dim() == 2 and input_ids.shape[1] == self.arch.max_positions, \
             "pad / truncate to max_length=%d as the reference's tokenizer call does" % self.arch.max_positions
+        import contextlib
         B = input_ids.shape[0]
-        plan = self._plans.get(B)
-        if plan is None:
-            plan = self._plans[B] = _Plan(self, B)
-        plan.ids.copy_(input_ids.reshape(-1).to(self.device))
-        stream = torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
-        if self.use_graph:
-            if plan.graph is None:
-                plan.graph = self.lib.graph_create(plan.prog)
-            self.lib.graph_launch(plan.graph, stream)
-        else:
-            self.lib.run(plan.prog, stream)
-        return (plan.out.view(B, plan.T, plan.C).clone(),)
+        # launches go to the device the weights live on, whatever the caller's current device is
+        with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
+            plan = self._plans.get(B)
+            if plan is None:
+                plan = self._plans[B] = _Plan(self, B)
+            plan.ids.copy_(input_ids.reshape(-1).to(self.device))
+            stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            if self.use_graph:
+                if plan.graph is None:
+                    plan.graph = self.lib.graph_create(plan.prog)
+                self.lib.graph_launch(plan.graph, stream)
+            else:
+                self.lib.run(plan.prog, stream)
+            return (plan.out.view(B, plan.T, plan.C).clone(),)
