@@ -282,3 +282,29 @@ def test_u8_pipeline_with_device_side_resize(gpu_lib):
     out_host = model.forward_u8(torch.from_numpy(host).cuda(), caption_enc=cap, eps=eps)
     assert out_dev.shape == (2, 72, 88, 3) and torch.equal(out_dev, out_host)
     _free(model)
+
+
+def test_tiny_random_shapes_fuzz(gpu_lib):
+    """Seeded sweep over batch and image sizes (any multiples of 8: odd latent planes, ragged tiles, planner routes that change
+    with the plane size) on the tiny architecture, fp32 against the oracle; pix2pix and both CycleGAN directions."""
+    import random
+    rnd = random.Random(20260922)
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    mc = make_cyclegan_weights(TINY_UNET, TINY_VAE, rank_unet=16)
+    p2p = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
+    cg = CycleGAN_Turbo(weights=gw(mc), device="cuda", dtype=torch.float32)
+    for it in range(10):
+        B, H, W = rnd.choice([1, 2, 3, 5]), 8 * rnd.randint(8, 26), 8 * rnd.randint(8, 26)
+        if it % 3 == 2:
+            x, cap, eps, _ = make_inputs("photo", B, H, W, TINY_UNET.cross_attention_dim, seed=it)
+            d = rnd.choice(["a2b", "b2a"])
+            ref = cyclegan_forward(mc, x, cap, eps, direction=d)
+            out = cg(x.cuda(), direction=d, caption_emb=cap.cuda(), eps=eps.cuda())
+            name = f"fuzz cyclegan {d} B={B} {H}x{W}"
+        else:
+            x, cap, eps, _ = make_inputs("canny", B, H, W, TINY_UNET.cross_attention_dim, seed=it)
+            ref = pix2pix_forward(mw, x, cap, eps)
+            out = p2p(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+            name = f"fuzz pix2pix B={B} {H}x{W}"
+        assert report(name, out, ref) < 1e-3
+    _free(p2p, cg)
