@@ -8,7 +8,7 @@
 TAG=${1:-r2}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
-cp $O/${TAG}_trace/*/trace_kernel_stats.csv $O/${TAG}_bench_bs8_kernel_stats.csv 2>/dev/null || cp $O/${TAG}_trace/trace_kernel_stats.csv $O/${TAG}_bench_bs8_kernel_stats.csv
+cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
 F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/${TAG}_write -name "*counter_collection.csv" | head -1)
@@ -32,3 +32,10 @@ PY
 done
 head -8 $O/${TAG}_bench_bs8_kernel_stats.csv | cut -c1-180
 cat $O/${TAG}_traffic_conv3x3_halo.json
+# 5. bs=1 latency path: kernel-trace stats of the bs=1 bench (560 launches per forward)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bs1 -o trace -- python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-latency > /dev/null 2> $O/${TAG}_trace_bs1.err
+cp $(find $O/${TAG}_trace_bs1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs1_kernel_stats.csv
+# 6. SQ counters of the halo conv on its two characteristic shapes (one counter set per pass)
+bash benchmarks/pmc_conv.sh $O/${TAG}_pmc "vae 128->128@512 gn,vae 512->512@128 gn" > /dev/null 2>&1
+python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc/sq2 -name "*counter_collection.csv" | head -1) conv3x3_halo_kernel > $O/${TAG}_pmc_conv3x3_halo_summary.txt 2>&1
+cat $O/${TAG}_pmc_conv3x3_halo_summary.txt

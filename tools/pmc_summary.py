@@ -1,0 +1,34 @@
+"""Per-dispatch SQ counter summary of one kernel from rocprofv3 --pmc csv files (one file per counter set):
+
+    python tools/pmc_summary.py <sq1_counter_collection.csv> <sq2_counter_collection.csv> conv3x3_halo_kernel
+
+Prints, per (kernel instantiation, grid size): dispatches, the counters averaged per dispatch, and the derived ratios the
+design document quotes (MFMA busy share of the kernel's cycles, LDS bank-conflict share, wave-cycle split)."""
+import collections
+import csv
+import sys
+
+files, pat = sys.argv[1:-1], sys.argv[-1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        if pat not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"].split("(")[0][-70:], r["Grid_Size"])
+        c = agg[key][r["Counter_Name"]]
+        c[0] += float(r["Counter_Value"])
+        c[1] += 1
+for key, cs in agg.items():
+    v = {k: a / max(n, 1) for k, (a, n) in cs.items()}
+    n = max(n for _, n in cs.values())
+    print("%s grid %s  (%d dispatches)" % (key[0], key[1], n))
+    print("   " + "  ".join("%s %.3g" % (k, x) for k, x in sorted(v.items())))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, MFMA busy over the 1024 SIMDs
+        print("   MFMA busy share of kernel cycles: %.1f %%" % (100 * (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (v["GRBM_GUI_ACTIVE"] / 8)))
+    if "SQ_LDS_BANK_CONFLICT" in v and v.get("SQ_LDS_IDX_ACTIVE"):
+        print("   LDS bank-conflict share of LDS cycles: %.1f %%" % (100 * v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"]))
+    if "SQ_WAVE_CYCLES" in v:
+        w = v["SQ_WAVE_CYCLES"]
+        print("   wave cycles: parked (waitcnt/barrier) %.1f %%  issue-stalled %.1f %%  issuing %.1f %%" % (
+            100 * v.get("SQ_WAIT_ANY", 0) / w, 100 * v.get("SQ_WAIT_INST_ANY", 0) / w, 100 * v.get("SQ_ACTIVE_INST_ANY", 0) / w))
