@@ -1,4 +1,5 @@
 #!/bin/bash
+# (every rocprofv3 pass runs under `timeout`: a PMC pass once hung a box for 30 minutes)
 # Round evidence set, from the repo root on the GPU box:  benchmarks/final_round.sh r2   (writes gpurun_out/<tag>_*)
 #   1. the bench line of the headline configuration (cfg 2) with the CPU oracle beside it and the parity of image 0
 #   2. rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / total / average)
@@ -7,10 +8,10 @@
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
 TAG=${1:-r2}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
 cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
 F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/${TAG}_write -name "*counter_collection.csv" | head -1)
 python tools/pmc_traffic.py $F $W conv3x3_halo_kernel --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
     --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3_halo.json
@@ -33,9 +34,9 @@ done
 head -8 $O/${TAG}_bench_bs8_kernel_stats.csv | cut -c1-180
 cat $O/${TAG}_traffic_conv3x3_halo.json
 # 5. bs=1 latency path: kernel-trace stats of the bs=1 bench (560 launches per forward)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bs1 -o trace -- python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-latency > /dev/null 2> $O/${TAG}_trace_bs1.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bs1 -o trace -- python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-latency > /dev/null 2> $O/${TAG}_trace_bs1.err
 cp $(find $O/${TAG}_trace_bs1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs1_kernel_stats.csv
 # 6. SQ counters of the halo conv on its two characteristic shapes (one counter set per pass)
-bash benchmarks/pmc_conv.sh $O/${TAG}_pmc "vae 128->128@512 gn,vae 512->512@128 gn" > /dev/null 2>&1
+timeout 600 bash benchmarks/pmc_conv.sh $O/${TAG}_pmc "vae 128->128@512 gn,vae 512->512@128 gn" > /dev/null 2>&1
 python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc/sq2 -name "*counter_collection.csv" | head -1) conv3x3_halo_kernel > $O/${TAG}_pmc_conv3x3_halo_summary.txt 2>&1
 cat $O/${TAG}_pmc_conv3x3_halo_summary.txt
