@@ -308,3 +308,23 @@ def test_tiny_random_shapes_fuzz(gpu_lib):
             name = f"fuzz pix2pix B={B} {H}x{W}"
         assert report(name, out, ref) < 1e-3
     _free(p2p, cg)
+
+
+def test_non_current_device(gpu_lib):
+    """A model built for cuda:1 must launch there while cuda:0 is the current device (plan / packer / text encoder wrap their
+    launches in the owning device's context).  Needs two GPUs: skipped on the 1-GPU boxes this suite usually runs on."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 2, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    torch.cuda.set_device(0)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda:1", dtype=torch.float32)
+    out = model(x.to("cuda:1"), caption_enc=cap.to("cuda:1"), eps=eps.to("cuda:1"), deterministic=True)
+    assert out.device.index == 1 and torch.cuda.current_device() == 0
+    assert report("tiny pix2pix on cuda:1 with cuda:0 current", out, ref) < 1e-3
+    model.set_lora_scale(0.5)
+    model.set_lora_scale(1.0)
+    out2 = model(x.to("cuda:1"), caption_enc=cap.to("cuda:1"), eps=eps.to("cuda:1"))
+    assert torch.equal(out, out2)
+    _free(model)
