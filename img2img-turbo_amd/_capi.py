@@ -36,8 +36,7 @@ class IgemmParams(C.Structure):
 class GnStatsParams(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("c0", i32), ("c1", i32), ("ld0", i32), ("ld1", i32),
                 ("nimg", i32), ("hw", i32), ("groups", i32), ("eps", f32),
-                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp), ("finalize_only", i32),
-                ("y", vp), ("ldy", i32), ("act", i32)]
+                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp), ("finalize_only", i32)]
 
 
 class GnApplyParams(C.Structure):
@@ -177,7 +176,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 4:
+        if L.i2i_abi_version() != 3:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

@@ -307,54 +307,9 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
     for (int c = tid; c < nch; c += 256) {
         const int g = c / cpg, cc = c_first + c;
         const float sc = gst[2 * g + 1] * p.gamma[cc];
-        const float sh = p.beta[cc] - gst[2 * g] * sc;
         float* o = p.ss + ((int64_t)img * ct + cc) * 2;
         o[0] = sc;
-        o[1] = sh;
-        chs[2 * c] = sc;                          // the per-channel sums are consumed: keep (scale, shift) for the apply sweep
-        chs[2 * c + 1] = sh;
-    }
-    // ---- optional second sweep: y[..., channel] = act(x * scale + shift) for this block's channels (the materialised operand
-    // of a consumer that stages by LDS-DMA): the tensor was just read, so this sweep is served from L2, and the separate
-    // gn_apply launch (a few microseconds each, ~100 of them in a batch-1 forward) disappears
-    if (p.y == nullptr) return;
-    __syncthreads();
-    if (prow < ppb) {
-        const int c = c_first + unit * 8;
-        const T* src = (c < p.c0) ? (const T*)p.x0 + (int64_t)img * p.hw * p.ld0 + c
-                                  : (const T*)p.x1 + (int64_t)img * p.hw * p.ld1 + (c - p.c0);
-        const int ld = (c < p.c0) ? p.ld0 : p.ld1;
-        T* dst = (T*)p.y + (int64_t)img * p.hw * p.ldy + c;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = chs[2 * (unit * 8 + e)]; sh[e] = chs[2 * (unit * 8 + e) + 1]; }
-        constexpr int UNR = 4;
-        for (int px0 = prow; px0 < p.hw; px0 += ppb * UNR) {
-            chunk_t v[UNR][8 / EPC];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int px = px0 + u * ppb;
-#pragma unroll
-                for (int h = 0; h < 8 / EPC; ++h)
-                    v[u][h] = (px < p.hw) ? *(const chunk_t*)(src + (int64_t)px * ld + h * EPC) : zero_chunk<T>();
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int px = px0 + u * ppb;
-                if (px >= p.hw) continue;
-#pragma unroll
-                for (int h = 0; h < 8 / EPC; ++h) {
-                    chunk_t o;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        float f = to_f32<T>(v[u][h][e]) * sc[h * EPC + e] + sh[h * EPC + e];
-                        if (p.act == 1) f = silu_f(f);
-                        o[e] = from_f32<T>(f);
-                    }
-                    *(chunk_t*)(dst + (int64_t)px * p.ldy + h * EPC) = o;
-                }
-            }
-        }
+        o[1] = p.beta[cc] - gst[2 * g] * sc;
     }
 }
 
@@ -420,7 +375,6 @@ int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
         }
     }
     const int ct = p.c0 + p.c1;
-    if (p.y) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: the fused apply (y) needs the single-launch path (hw * channels <= 3M, 4..16 groups per block forming 8-channel units, not finalize_only)");
     if (!p.finalize_only) {
         hipLaunchKernelGGL((gn_partial_kernel<T>), dim3((unsigned)p.nparts, (unsigned)p.nimg), dim3(256), (size_t)ct * 8, s, p);
         const int rc = i2i::check_launch("gn_partial");
@@ -445,7 +399,6 @@ extern "C" int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* strea
     if (p->c0 % 8 || p->c1 % 8 || p->ld0 % 8 || (p->x1 && p->ld1 % 8)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: channels must be multiples of 8");
     if (ct % p->groups || ct > GN_JMAX * 64 * 8 || p->groups > 256 || p->nparts < 1) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: bad geometry (ct=%d groups=%d)", ct, p->groups);
     if ((p->c1 != 0) != (p->x1 != nullptr)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: x1/c1 mismatch");
-    if (p->y && (p->ldy < ct || p->ldy % 8)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_stats: bad ldy for the fused apply");
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case I2I_F32: return gn_stats_t<float>(*p, s);

@@ -73,7 +73,7 @@ class ForwardPlan:
     of the plan: it lives in the packers' device scalars (Packer.set_scale), so one plan (and its hipGraph) serves every r."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True, fuse_gn_apply=True):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         # H, W multiples of 8 suffice (src/inference_paired.py:38-41): latent sizes that are not multiples of 8 make the
         # UNet levels odd (70 -> 35 -> 18 -> 9), handled like diffusers' forward_upsample_size path (explicit sizes).
@@ -83,7 +83,6 @@ class ForwardPlan:
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
         self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
-        self.fuse_gn_apply = fuse_gn_apply and not debug    # small tensors: the single-launch GN statistics kernel also writes act(GN(x))
         self.fuse_vae_attention = fuse_vae_attention   # d = 512 flash kernel for the VAE mid-block attention (16-bit types)
         self.halo_min_tiles = halo_min_tiles   # fewer halo-conv tiles than this: LDS-DMA igemm + split-K instead
         self.subpix = subpix         # Upsample2D convs in sub-pixel form (4 parity 2x2 convs on the source plane)
@@ -179,7 +178,6 @@ class ForwardPlan:
                                 c0=x.c, ld0=x.c, finalize_only=1)
                 self._pending_gn.append((op[1], "stats_ss"))
                 self._add(op, (label or norm_name) + ".finalize")
-                self._last_stats = None
                 return
         nparts = int(min(256, max(1, (x.hw * ct) // 65536)))
         self._gn_scratch(x.n, ct, nparts, groups)
@@ -187,17 +185,6 @@ class ForwardPlan:
                         x1=x1.t if x1 else None, c0=x.c, c1=x1.c if x1 else 0, ld0=x.c, ld1=x1.c if x1 else 0)
         self._pending_gn.append((op[1], "stats"))
         self._add(op, label or norm_name)
-        # remembered for conv(): when the consumer needs act(GN(x)) MATERIALISED and this op takes the single-launch
-        # small-tensor kernel, that kernel writes it in a second sweep (no gn_apply launches)
-        self._last_stats = (op[1], x, x1, self._gn_single_launch(x.hw, ct, groups))
-
-    @staticmethod
-    def _gn_single_launch(hw, ct, groups):
-        """Mirrors gn_stats_t (csrc/norm.hip): the single-launch kernel takes tensors of <= 3M elements whose groups pack into
-        4 / 8 / 16 per block forming whole 8-channel units."""
-        cpg = ct // groups
-        gpb = next((c for c in (4, 8, 16) if groups % c == 0 and (c * cpg) % 8 == 0 and (c * cpg) // 8 <= 256), 0)
-        return bool(gpb) and hw * ct <= (3 << 20)
 
     def _splitk(self, M, N, Kd):
         """Split-K factor + fp32 slab for the weight-streaming shapes (few rows, K in the thousands); mirrors the
@@ -262,24 +249,13 @@ class ForwardPlan:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
             # UNet planes / 1x1 projections has no operand prologue, and the extra pass is over a few MB at most
             ct = x.c + c1
-            ls = getattr(self, "_last_stats", None)
-            own_y = False
-            if self.fuse_gn_apply and ls is not None and ls[1] is x and ls[2] is x1 and ls[3] and not ls[0].y:
-                # the statistics op of this very tensor is a single-launch kernel: let it write the operand as well.  That op
-                # sits EARLIER in the program than this point, so the buffer is a dedicated one (a pooled buffer could have
-                # been lent to an op recorded in between, e.g. a split-K slab of the shortcut conv); <= 6 MB each
-                y = Act(torch.empty(x.n * x.h * x.w * ct, dtype=self.dtype, device=self.device), x.n, x.h, x.w, ct)
-                self._keep.append(y.t)
-                own_y = True
-                ls[0].y, ls[0].ldy, ls[0].act = y.t.data_ptr(), ct, act
-            else:
-                y = self.new(x.n, x.h, x.w, ct)
-                for src, coff in ((x, 0), (x1, x.c)):
-                    if src is None:
-                        continue
-                    op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
-                    self._pending_gn.append((op[1], "apply"))
-                    self._add(op, label + ".gn_apply")
+            y = self.new(x.n, x.h, x.w, ct)
+            for src, coff in ((x, 0), (x1, x.c)):
+                if src is None:
+                    continue
+                op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+                self._pending_gn.append((op[1], "apply"))
+                self._add(op, label + ".gn_apply")
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         M, N, Kd = x.n * ho * wo, pw["n"], ks * ks * (x.c + c1)
         splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
@@ -301,7 +277,7 @@ class ForwardPlan:
             self.halo_flops_real = getattr(self, "halo_flops_real", 0) + (fl * 4 // 9 if subpix else fl)
         self._add(op, label, fl, kernel=kname)
         self.taps[label] = out
-        if gn and not fused and not own_y:
+        if gn and not fused:
             self.free(x_in0)
         self.flops += fl
         return out

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 4
+#define I2I_ABI_VERSION 3
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -115,9 +115,6 @@ typedef struct {
     float* partial; int32_t nparts;
     float* ss;                                /* out [nimg][c0+c1][2] */
     int32_t finalize_only;                    /* 1: `partial` was produced by a conv epilogue (gn_part); x0 unused */
-    void* y; int32_t ldy, act;                /* optional fused apply (single-launch small-tensor path only): y[img][px][0 .. c0+c1) =
-                                                 act(x * scale + shift) with pixel stride ldy; act 1 = SiLU.  What I2I_OP_GN_APPLY would
-                                                 do in one or two more launches; an op that cannot take the single-launch path is refused */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its

@@ -335,14 +335,3 @@ def test_lanczos_resize_u8_is_bit_identical_to_pillow(emu_lib):
     a = rng.integers(0, 256, (1, 37, 53, 3), dtype=np.uint8)
     got = resize_to_multiple_of_8(torch.from_numpy(a), emu_lib).numpy()
     assert np.array_equal(got[0], np.asarray(Image.fromarray(a[0], "RGB").resize((48, 32), Image.LANCZOS)))
-
-
-def test_gn_stats_fused_apply(emu_lib):
-    """The single-launch GroupNorm statistics kernel also writes act(GN(x)) (what a separate gn_apply launch did): plain and
-    concat sources, with and without SiLU; an op that cannot take the single-launch path refuses the request."""
-    from img2img_turbo_amd._capi import I2IError
-    oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, n=2, c0=64, groups=16, h=12, w=9, fused_apply=1)
-    oc.check_gn_stats(emu_lib, "cpu", torch.float32, n=1, c0=64, c1=32, groups=8, h=7, w=10, fused_apply=1)      # concat [x | skip]
-    oc.check_gn_stats(emu_lib, "cpu", torch.float16, n=3, c0=320, groups=32, h=8, w=8, fused_apply=0)             # cpg 10, GN without SiLU
-    with pytest.raises(I2IError):
-        oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, n=1, c0=24, groups=3, h=8, w=8, fused_apply=1)          # 3 groups: no single-launch kernel

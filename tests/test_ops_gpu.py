@@ -208,11 +208,3 @@ def test_lanczos_resize_u8_is_bit_identical_to_pillow(gpu_lib):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print("[resize] 32 x 1280x720 -> 512x512: %.3f ms, %.0f GB/s of input+output bytes" % (dt * 1e3, (x.numel() + y.numel()) / dt / 1e9))
-
-
-@pytest.mark.gpu
-def test_gn_stats_fused_apply(gpu_lib):
-    """Single-launch GroupNorm statistics + act(GN(x)) in one kernel (UNet-level shapes, concat sources)."""
-    oc.check_gn_stats(gpu_lib, "cuda", torch.bfloat16, n=8, c0=320, groups=32, h=64, w=64, fused_apply=1)
-    oc.check_gn_stats(gpu_lib, "cuda", torch.bfloat16, n=1, c0=1280, c1=640, groups=32, h=32, w=32, fused_apply=1)
-    oc.check_gn_stats(gpu_lib, "cuda", torch.float32, n=2, c0=512, groups=32, h=33, w=41, fused_apply=0)
