@@ -28,8 +28,16 @@ therefore pinned only by (a) analytic known-answer tests (scheduler constants,
 time-embedding values, LoRA merged == unmerged, TwinConv folded == unfolded,
 zero skip-conv => skips inert, gamma=1 stochastic == deterministic), (b)
 exact parameter-count checks against the published SD-2.1/SD-Turbo sizes
-(865,910,724 UNet / 83,653,863 VAE parameters) and (c) for the CLIP text tower,
-the installed ``transformers`` implementation.  See tests/test_oracle_kats.py.
+(865,910,724 UNet / 83,653,863 VAE parameters), (c) for the CLIP text tower,
+the installed ``transformers`` implementation, and (d) for the LANCZOS resize of
+the callers (oracle/resize.py), the installed Pillow -- (c) and (d) ARE pinned,
+bit for bit in the case of (d).  See tests/test_oracle_kats.py.
+
+The way to a pin for the VAE / UNet path exists but cannot be walked here:
+tests/golden/make_reference_golden.py instantiates the reference's OWN classes
+on the CPU (patched ``from_pretrained`` / ``.cuda()``) where diffusers + peft are
+importable and writes fixtures that test_oracle_matches_reference_golden
+consumes.
 """
 
 from .arch import VAEArch, UNetArch, SD_TURBO_VAE, SD_TURBO_UNET, TINY_VAE, TINY_UNET  # noqa: F401
