@@ -112,3 +112,23 @@ def test_pix2pix_odd_latent_size_fp32(emu_lib):
     assert out.shape == ref.shape
     assert (out - ref).abs().max().item() < 1e-3
 
+
+
+@pytest.mark.slow
+def test_buffer_recycling_is_invisible(emu_lib, monkeypatch):
+    """The planner recycles activation buffers as soon as the static program no longer reads them (plan.Pool).  The same program
+    built with recycling switched off (every intermediate in its own buffer) must give bit-identical outputs: an op reading a
+    buffer that was re-lent too early would show here.  Deterministic and stochastic programs, odd plane sizes."""
+    from img2img_turbo_amd import plan as plan_mod
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 2, 72, 88, TINY_UNET.cross_attention_dim)
+    kw = dict(caption_enc=cap, eps=eps, deterministic=False, r=0.6, noise_map=nm)
+    shared = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.bfloat16, lib=emu_lib)
+    a = shared(x, **kw)
+    n_shared = len(next(iter(shared._plans.values())).pool.all)
+    monkeypatch.setattr(plan_mod.Pool, "put", lambda self, t: None)
+    fresh = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.bfloat16, lib=emu_lib)
+    b = fresh(x, **kw)
+    n_fresh = len(next(iter(fresh._plans.values())).pool.all)
+    assert n_fresh > 2 * n_shared, (n_fresh, n_shared)          # the switch really removed the sharing
+    assert torch.equal(a, b)
