@@ -46,7 +46,7 @@ class CycleGAN_Turbo(TurboGeneratorBase):
         self.vae_enc._model = self.vae_dec._model = self.unet._model = self
 
     @torch.no_grad()
-    def forward_u8(self, images_u8, *args, resize=None, resize_back=False, **kw):
+    def forward_u8(self, images_u8, *args, resize=None, resize_back=False, image_prep=None, **kw):
         """uint8 HWC in/out on the device: ``Normalize([0.5],[0.5])(to_tensor(img))`` (src/inference_unpaired.py:47) and
         ``ToPILImage()(out*0.5+0.5)`` (:53) run inside the boundary kernels.  ``resize=(width, height)`` applies the script's
         ``transforms.Resize(..., LANCZOS)`` (:40-47, e.g. (512, 512) for "resize_512x512") before the generator and
@@ -54,6 +54,10 @@ class CycleGAN_Turbo(TurboGeneratorBase):
         device and bit-identical to Pillow (image_ops.lanczos_resize_u8)."""
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
         in_hw = images_u8.shape[1:3]
+        if image_prep is not None:          # the script's build_transform(args.image_prep) (src/inference_unpaired.py:40, default "resize_512x512")
+            from .image_ops import apply_image_prep
+            with self._on_device():
+                images_u8 = apply_image_prep(images_u8, image_prep, self.lib)
         if resize is not None:
             from .image_ops import lanczos_resize_u8
             with self._on_device():

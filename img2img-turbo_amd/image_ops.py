@@ -100,3 +100,29 @@ def resize_to_multiple_of_8(images, lib=None):
     """src/inference_paired.py:38-41 on the device: LANCZOS resize to (w - w % 8, h - h % 8)."""
     h, w = images.shape[1], images.shape[2]
     return lanczos_resize_u8(images, (w - w % 8, h - h % 8), lib)
+
+
+def apply_image_prep(images, image_prep, lib=None):
+    """The inference-time options of the reference's ``build_transform`` (src/my_utils/training_utils.py:184-215, used at
+    src/inference_unpaired.py:40) on a uint8 HWC batch on the device:
+      "resize_512x512" / "resize_512", "resize_256x256" / "resize_256"  -> Resize((S, S), LANCZOS)
+      "resized_crop_512"  -> Resize(512, LANCZOS) (shorter side to 512, torchvision's size rule) then CenterCrop(512)
+      "no_resize"         -> identity
+    The random training augmentation ("resize_286_randomcrop_256x256_hflip") is out of scope (training)."""
+    h, w = images.shape[1], images.shape[2]
+    if image_prep == "no_resize":
+        return images
+    if image_prep in ("resize_256", "resize_256x256"):
+        return lanczos_resize_u8(images, (256, 256), lib)
+    if image_prep in ("resize_512", "resize_512x512"):
+        return lanczos_resize_u8(images, (512, 512), lib)
+    if image_prep == "resized_crop_512":
+        size = 512
+        short, long = (w, h) if w <= h else (h, w)
+        new_long = int(size * long / short)                      # torchvision _compute_resized_output_size
+        ow, oh = (size, new_long) if w <= h else (new_long, size)
+        r = lanczos_resize_u8(images, (ow, oh), lib)
+        top, left = int(round((oh - size) / 2.0)), int(round((ow - size) / 2.0))      # torchvision center_crop
+        return r[:, top:top + size, left:left + size].contiguous()
+    raise ValueError("image_prep %r is a training-time augmentation or unknown (supported: resize_256[x256], resize_512[x512], "
+                     "resized_crop_512, no_resize)" % (image_prep,))

@@ -335,3 +335,23 @@ def test_lanczos_resize_u8_is_bit_identical_to_pillow(emu_lib):
     a = rng.integers(0, 256, (1, 37, 53, 3), dtype=np.uint8)
     got = resize_to_multiple_of_8(torch.from_numpy(a), emu_lib).numpy()
     assert np.array_equal(got[0], np.asarray(Image.fromarray(a[0], "RGB").resize((48, 32), Image.LANCZOS)))
+
+
+def test_image_prep_options_match_the_reference_transforms(emu_lib):
+    """image_ops.apply_image_prep vs the reference's build_transform (src/my_utils/training_utils.py:184-215) restated with
+    Pillow: Resize((S, S), LANCZOS); Resize(512, LANCZOS) + CenterCrop(512) with torchvision's size / crop arithmetic."""
+    import numpy as np
+    from PIL import Image
+    from img2img_turbo_amd.image_ops import apply_image_prep
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (1, 90, 140, 3), dtype=np.uint8)
+    t = torch.from_numpy(a)
+    pil = Image.fromarray(a[0], "RGB")
+    assert np.array_equal(apply_image_prep(t, "resize_256x256", emu_lib)[0].numpy(), np.asarray(pil.resize((256, 256), Image.LANCZOS)))
+    assert torch.equal(apply_image_prep(t, "no_resize", emu_lib), t)
+    # shorter side (height 90) -> 512, width int(512 * 140 / 90) = 796, centre crop 512: left = round((796 - 512) / 2) = 142
+    want = np.asarray(pil.resize((796, 512), Image.LANCZOS))[:, 142:142 + 512]
+    got = apply_image_prep(t, "resized_crop_512", emu_lib)[0].numpy()
+    assert got.shape == (512, 512, 3) and np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        apply_image_prep(t, "resize_286_randomcrop_256x256_hflip", emu_lib)
