@@ -87,7 +87,7 @@ def kernel_roofline(plan, dtype_name, reps=2):
         with open(PER_OP_PATH, "w") as f:
             for t, label, kn, fl in rows:
                 f.write("%8.4f ms  %7.1f TF  %-28s %s\n" % (t, fl / (t * 1e-3) / 1e12 if t > 0 else 0.0, kn[:28], label))
-    halo = [k for k in fam if k.startswith("conv3x3_halo_kernel")]
+    halo = [k for k in fam if k.startswith("conv3x3_")]       # conv3x3_w32_kernel + conv3x3_halo_kernel[<SUBPIX>]
     t3 = sum(fam[k][0] for k in halo)
     f3 = sum(fam[k][1] for k in halo)
     n3 = sum(fam[k][2] for k in halo)
@@ -100,7 +100,10 @@ def kernel_roofline(plan, dtype_name, reps=2):
         # only for the build and workload the counters were collected on; anything else reports null rather than a stale number
         if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name and tj.get("size") == plan.H and tj.get("source_hash") == source_hash():
             traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("collected")
-    roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel (halo-tiled 3x3 implicit-GEMM conv, incl. sub-pixel upsampler form)",
+    roof = {"bound": "mfma", "kernel": "conv3x3_w32_kernel + conv3x3_halo_kernel (every 3x3 stride-1 conv of the step: wide-tile 32x32x16-MFMA kernel, "
+                                       "halo kernel for small planes and the sub-pixel upsampler form)",
+            "per_kernel": {k: {"launches": fam[k][2], "avg_launch_ms": round(fam[k][0] / fam[k][2], 4),
+                               "tflops": round(fam[k][1] / (fam[k][0] * 1e-3) / 1e12, 1)} for k in halo},
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, MI355X_MICROARCH.md HBM section)",
             "traffic_source": traffic_src,

@@ -100,7 +100,8 @@ def main():
                 tr = ws.view(-1, 16).cpu().double()
                 tr = tr[tr.sum(1) > 0]
                 tot = tr.sum(1).mean().item()
-                names = ["kgroup0", "vmcnt", "barrier", "issue", "kgroup1", "handover", "pro:setup+w0read", "epi:gnstats", "pro:setup+issue", "pro:vmcnt0", "pro:barrier", "pro:halo_store", "pro:barrier2",
+                w32 = tile >= 40 or (tile == 0 and tr[:, 8:].sum() == 0)       # the wide-tile kernel writes 8 segments, the halo kernel 16
+                names = ["prologue", "k16 steps 0-2", "vmcnt wait", "step barrier", "window+k16 step 3", "slab barrier+reads", "epilogue", "-"] + ["-"] * 8 if w32 else ["kgroup0", "vmcnt", "barrier", "issue", "kgroup1", "handover", "pro:setup+w0read", "epi:gnstats", "pro:setup+issue", "pro:vmcnt0", "pro:barrier", "pro:halo_store", "pro:barrier2",
                          "epi:tail_vmcnt", "epi:bias+store", "-"]
                 print("   trace: %d waves, %.0f cycles/wave (%.2f GHz if the wave spans the launch): " % (len(tr), tot, tot / (t * 1e-3) / 1e9) +
                       "  ".join("%s %.1f%%" % (n, 100 * tr[:, i].mean().item() / tot) for i, n in enumerate(names)), flush=True)

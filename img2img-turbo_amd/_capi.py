@@ -111,7 +111,7 @@ _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply"
              OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed",
              OP_LORA_MERGE: "lora_merge", OP_RESIZE_U8: "resize_u8"}
 
-EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_gn_stats",
+EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_igemm_route", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
            "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
@@ -171,12 +171,14 @@ class Library:
             getattr(L, name).restype = C.c_int
         L.i2i_igemm_gn_parts.argtypes = [vp, C.c_int, C.c_int]
         L.i2i_igemm_gn_parts.restype = C.c_int
+        L.i2i_igemm_route.argtypes = [vp, C.c_int]
+        L.i2i_igemm_route.restype = C.c_char_p
         L.i2i_run.argtypes = [vp, C.c_int, vp]
         L.i2i_run_timed.argtypes = [vp, C.c_int, vp, vp]
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 3:
+        if L.i2i_abi_version() != 4:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))
@@ -190,6 +192,10 @@ class Library:
     def igemm_gn_parts(self, params, dtype_code, groups):
         """Partial-sum slots per image the igemm op would write through gn_part (0 = its kernel cannot)."""
         return int(self.lib.i2i_igemm_gn_parts(C.addressof(params), dtype_code, groups))
+
+    def igemm_route(self, params, dtype_code):
+        """Kernel family i2i_igemm() will run this op on (reporting only)."""
+        return self.lib.i2i_igemm_route(C.addressof(params), dtype_code).decode()
 
     def run(self, prog, stream=0):
         self.check(self.lib.i2i_run(C.addressof(prog.array), prog.n, vp(stream)))

@@ -12,10 +12,14 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["igemm.hip", "conv3x3.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
 HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
 LIB = os.path.join(HERE, "libi2i_turbo.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# per-source flags.  conv3x3_w32: the GroupNorm+SiLU VALU runs in the MFMA shadow at one wave per SIMD, where packed-f32
+# VALU (v_pk_mul_f32 / v_pk_add_f32, what SLP vectorisation makes of adjacent scalar ops) costs more than two scalar ops
+# (MI355X_MICROARCH.md "price of one filler beside MFMAs")
+EXTRA_FLAGS = {"conv3x3_w32.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out, deps):
@@ -29,7 +33,7 @@ def _compile(src, force, bdir="build", defs=()):
     obj = os.path.join(HERE, bdir, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = ["hipcc"] + FLAGS + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
+        cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -1,0 +1,567 @@
+// 3x3 stride-1 pad-1 implicit-GEMM convolution, "wide" operating point for gfx950: 32x32x16 MFMA, wave tiles of
+// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file) at ONE wave per SIMD,
+// or 128 x 64 / 64 x 128 at two.  Same replaced reference ops as conv3x3.hip (F.conv2d of diffusers ResnetBlock2D /
+// Upsample2D with the preceding F.group_norm + F.silu, torch.cat and nearest-2x folded into the operand staging,
+// bias / residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode
+// and planes narrower than 32 stay on conv3x3_halo_kernel).
+//
+// Why a second operating point: the 64x64 wave tile on 16x16x32 MFMAs at two waves per SIMD is
+// issue bound -- per 32 MFMAs (512 matrix cycles) a wave issues 16 ds_read_b128, its DMA share, waits and a barrier.
+// Here a k16 step is 16 MFMAs of 32 cycles (512 matrix cycles) against 8 ds_read_b128: half the LDS traffic and half
+// the MFMA instructions per FLOP, and with 8 issue slots per MFMA and nobody else on the SIMD the GroupNorm+SiLU of
+// the NEXT slab's halo runs in the MFMA shadow instead of in a serial hand-over.
+//
+// Workgroup = TH x 32 output pixels of one image x BN channels; WM x WN waves, wave = FM tile rows (one 32-pixel
+// fragment each) x FN 32-channel fragments.  K loop = (64-channel slab) x (9 taps) x (4 k16 steps):
+//   * pixels: the (TH+2) x 34 halo of a slab is staged once (16-byte loads hidden from the compiler's waitcnt
+//     bookkeeping -> GN affine + SiLU in registers, spread over the taps -> ds_write_b128 at the slab hand-over);
+//     tap (dy,dx) reads 32 consecutive 128-byte LDS rows starting at (row+dy)*34+dx, lanes 0-31 the even chunk of the
+//     k16 step and lanes 32-63 the odd one.  XOR swizzle chunk ^ ((row>>1)&7): conflict-free for every start row
+//     (tools/lds_bank_model.py).
+//   * weights [N][9*Cin]: LDS-DMA into a 3-deep ring of [BN][64] slabs, swizzle carried by the per-lane source
+//     address, issued right after the step barrier that frees the slot and waited for two steps later with a counted
+//     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free (tail steps re-fetch valid
+//     weights that nobody reads), so the counts are exact.
+//   * ONE s_barrier per step, between k16 steps 2 and 3; fragment reads run one k16 step ahead of their MFMAs.
+//   * MFMA operands swapped (A = weight rows) so an accumulator lane owns 4 consecutive channels of one pixel per
+//     register quad; quads are half-exchanged with v_permlane32_swap so every lane stores 16 bytes.
+#include "i2i_dev.h"
+#include "launch.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int V> struct icw { static constexpr int value = V; };
+template <int N, class F> __device__ __forceinline__ void static_for_w(F&& f) {
+    if constexpr (N > 0) {
+        static_for_w<N - 1>(f);
+        f(icw<N - 1>{});
+    }
+}
+
+__device__ __forceinline__ int swz3(int row) { return (row >> 1) & 7; }
+
+constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
+// bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
+constexpr int w32_plane(int th) { return (((th + 2) * (W32_TW + 2) * 32 + 127) / 128) * 128 + 32; }
+
+// GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
+template <typename T, int TH, int BN, int WM, int WN, bool GN>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p) {
+    constexpr int TW = W32_TW, CK = W32_CK, RING = W32_RING, NTAPS = 9;
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int HW2 = TW + 2, HALO = (TH + 2) * HW2;
+    static_assert(TH % WM == 0 && BN % (32 * WN) == 0, "");
+    constexpr int FM = TH / WM, WTN = BN / WN, FN = WTN / 32;
+    constexpr int HPT = (HALO * 8 + NT - 1) / NT;      // halo chunks per thread per slab
+    constexpr int NPIECE = BN / 8;                     // 1-KiB LDS-DMA pieces per weight slab
+    static_assert(NPIECE % NW == 0, "every wave issues the same number of DMA pieces");
+    constexpr int BPW = NPIECE / NW;
+    constexpr int PLANE = w32_plane(TH);
+    typedef typename Elem<T>::chunk_t chunk_t;
+    static_assert(Elem<T>::EPC == 8, "16-bit dtypes only");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA destinations are scalar arithmetic
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int kc = tid & 7;
+    // Measurement hook (csrc/build.py --tag trace --defs=-DI2I_TRACE=1; never in the product build): every wave sums the
+    // shader cycles (s_memtime) it spends per pipeline segment and writes them to p.ws [workgroup][wave][16]:
+    // 0 prologue, 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3, 5 slab-end barrier + first
+    // reads, 6 epilogue.  p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 8 no MFMAs.
+#ifdef I2I_TRACE
+    unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tr_t = (unsigned)__builtin_amdgcn_s_memtime();
+#define W32_TR(k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; } while (0)
+#define W32_ABL(bit) ((p.splitk & (bit)) != 0)
+#else
+#define W32_TR(k) do { } while (0)
+#define W32_ABL(bit) false
+#endif
+
+    // ---- XCD-aware tile id (bijective for any grid): every XCD gets one contiguous run of tiles, channel tiles fastest
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tn = bid % ntn; bid /= ntn;
+    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * TH;
+    const int img = bid / tiles_y;
+    const int n0 = tn * BN;
+
+    const T* __restrict__ a0 = (const T*)p.a0;
+    const T* __restrict__ a1 = (const T*)p.a1;
+    const T* __restrict__ bw = (const T*)p.b;
+    const int cin = p.c0 + p.c1;
+    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
+
+    // LDS map.  Halo: FOUR planes, one per k16 step (channels 16*kk .. +15 of the slab), rows of 32 bytes = 2 chunks,
+    // chunk h of row r at physical chunk h ^ ((r>>3)&1): a fragment read (32 consecutive rows, lanes 0-31 chunk 0,
+    // lanes 32-63 chunk 1) is conflict-free for every start row, and the k16 step is a pure immediate offset.  PLANE
+    // = 32 (mod 128) so that the eight chunks of one pixel (8 consecutive lanes of a ds_write_b128) hit distinct banks.
+    // | 4 planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring | GN consts | bias |
+    constexpr int HS0 = 0;
+    constexpr int DUM0 = 4 * PLANE;
+    constexpr int BS0 = DUM0 + 1024;
+    constexpr int SS0 = BS0 + RING * BN * 128;          // [cin][2] fp32
+    const int BI0 = SS0 + (GN ? cin * 8 : 0);           // [BN] fp32
+    char* Bs = i2i_smem + BS0;
+    const bool bias_lds = p.bias_mode == 1;
+
+    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
+    // hpix = pixel index inside image `img` (0 for zero padding, flagged in padmask: conv pads the ACTIVATED tensor).
+    unsigned hpix[HPT], padmask = 0;
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) {
+        const int hp = (tid >> 3) + j * (NT / 8);
+        unsigned pix = 0;
+        bool pad = true;
+        if (hp < HALO) {
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
+            if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up) {
+                pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
+                pad = false;
+            }
+        }
+        hpix[j] = pix;
+        padmask |= (pad ? 1u : 0u) << j;
+    }
+    const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
+    const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
+    // LDS store address of chunk j: st_off + j * (NT/8)*32 (row bit 3 does not change with j); the last chunk row
+    // may run past the halo: those lanes store into the dummy block
+    const int st_off = HS0 + (kc >> 1) * PLANE + (tid >> 3) * 32 + (((kc & 1) ^ (((tid >> 3) >> 3) & 1)) << 4);
+    const int st_last = ((tid >> 3) + (HPT - 1) * (NT / 8) < HALO) ? st_off + (HPT - 1) * (NT / 8) * 32 : DUM0 + lane * 16;
+
+    // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3), physical
+    // chunk lane&7 = source chunk (lane&7) ^ swz3(row).  Rows past N are clamped (their columns are never stored).
+    unsigned b_voff[BPW];
+#pragma unroll
+    for (int q = 0; q < BPW; ++q) {
+        const int row = (wave + q * NW) * 8 + (lane >> 3);
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        b_voff[q] = (unsigned)(n * p.ldb + (((lane & 7) ^ swz3(row)) * 8)) * (unsigned)sizeof(T);
+    }
+    const int nslab = cin / CK;
+    // step index (slab*9 + tap) may run past the last one at the tail: those fetch slab 0 again (valid, never read)
+    auto b_dma_q = [&](int slab, int tap, int buf, int q) __attribute__((always_inline)) {
+        const int sl = slab < nslab ? slab : 0;
+        const char* src = (const char*)(bw + (tap * cin + sl * CK));
+        glds16_sv(src, b_voff[q], Bs + buf * BN * 128 + (wave + q * NW) * 1024);
+    };
+
+    chunk_t rh[HPT];
+    // One 16-byte load per call, always and branch-free (padding lanes read pixel 0 and are zeroed by the transform)
+    auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
+        const int ci = slab * CK;
+        const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
+        const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
+        const unsigned voff = hpix[j] * ldb + (unsigned)kc * 16u;
+        if (hidden) gload16_uncounted(rh[j], base, voff);
+        else rh[j] = *(const chunk_t*)(base + voff);
+    };
+    // GroupNorm affine + SiLU of one parked chunk, in place; padding chunks become exact zeros
+    float ssr[16];                                      // (scale, shift) of this thread's 8 channels, slab being staged
+    auto load_ssr = [&](int slab) __attribute__((always_inline)) {
+        if constexpr (GN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + (slab * CK + kc * 8) * 8 + q * 16);
+                ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
+            }
+        }
+    };
+    auto halo_xform = [&](int j) __attribute__((always_inline)) {
+        chunk_t c = rh[j];
+        if constexpr (GN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c[e] = from_f32<T>(silu_f(__builtin_fmaf(to_f32<T>(c[e]), ssr[2 * e], ssr[2 * e + 1])));
+        }
+        rh[j] = ((padmask >> j) & 1u) ? zero_chunk<T>() : c;
+    };
+    auto halo_store = [&](int j) __attribute__((always_inline)) {
+        *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * (NT / 8) * 32)) = rh[j];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: weights of steps 0..2, GN constants of every input channel, bias, halo of slab 0
+#pragma unroll
+    for (int t = 0; t < RING; ++t)
+#pragma unroll
+        for (int q = 0; q < BPW; ++q) b_dma_q(0, t, t, q);
+    if constexpr (GN) {
+        for (int pc = wave; pc * 128 < cin; pc += NW)      // 1 KiB = (scale, shift) of 128 channels per piece
+            if (pc * 128 + lane * 2 < cin) glds16(p.gn_ss + ((int64_t)img * cin + pc * 128 + lane * 2) * 2, i2i_smem + SS0 + pc * 1024);
+    }
+    if (bias_lds && wave == NW - 1) {
+#pragma unroll
+        for (int q = 0; q < (BN + 255) / 256; ++q) {
+            if (q * 256 + lane * 4 < BN) {
+                int n = n0 + q * 256 + lane * 4;
+                n = n + 4 <= p.N ? n : p.N - 4;          // lanes past a ragged tile's end re-read its last quad (never stored)
+                glds16(p.bias + n, i2i_smem + BI0 + q * 1024);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
+    wait_vmcnt<0>();
+    lds_barrier();
+    load_ssr(0);
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
+    lds_barrier();
+
+    // ---- per-lane LDS read bases.  Pixel fragment row = u + c with u = wm*FM*34 + l31 (lane) and c = (i+dy)*34 + dx
+    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only: 16 bases x_off[c & 15]; the row part of c and
+    // the k16 plane enter as the immediate c*32 + kk*PLANE.
+    int x_off[16];
+    {
+        const int u = wm * FM * HW2 + l31;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x_off[m] = HS0 + u * 32 + ((lh ^ (((u + m) >> 3) & 1)) << 4);
+    }
+    const int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
+
+    chunk_t xf[2][FM], wf[2][FN];
+    auto xread = [&](int tap, int i, int kk) __attribute__((always_inline)) -> chunk_t {
+        const int c = (i + tap / 3) * HW2 + tap % 3;
+        return *(const chunk_t*)(i2i_smem + x_off[c & 15] + (kk * PLANE + c * 32));
+    };
+    auto wread = [&](int buf, int j, int kk) __attribute__((always_inline)) -> chunk_t {
+        return *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + buf * BN * 128 + j * 4096);
+    };
+
+    // Halo chunks of the NEXT slab: loaded in the windows of taps 0..5 (chunks t, t+6, ...: a load issued after P_t is
+    // covered by the counted wait of P_{t+2}), transformed during step t+3 (q-th chunk of the window beside k16 step q),
+    // stored after P_8 -- when every fragment read of the current halo has completed -- in the shadow of the slab's
+    // last 16 MFMAs.  ONE extra barrier per slab, no serial hand-over.
+    constexpr int LW = 6;
+    auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c; return c; };
+    static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
+
+    // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
+    // reads of the NEXT k16 step go out beside its first MFMAs (weights first: the i-major MFMA order needs every weight
+    // fragment and x[0] at once); `post` (DMA pieces / halo stores: LDS writers, which the scheduler keeps behind the
+    // reads issued before them) one per MFMA after that.
+    auto kstep = [&](auto tapc, auto kkc, auto&& pre, auto has_pre_c, auto&& post, auto npost_c) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+        constexpr int cur = kk & 1, nxt = cur ^ 1;
+        constexpr bool xnext = kk < 3 || tap < NTAPS - 1;          // not across the slab hand-over
+        constexpr int ntap = kk < 3 ? tap : tap + 1, nkk = (kk + 1) & 3;
+        pre();
+        wf[nxt][0] = wread(ntap % RING, 0, nkk);                  // 9 % 3 == 0: the next slab's tap 0 too
+        if constexpr (xnext) xf[nxt][0] = xread(ntap, 0, nkk);
+#pragma unroll
+        for (int j = 1; j < FN; ++j) wf[nxt][j] = wread(ntap % RING, j, nkk);
+        if constexpr (xnext) {
+#pragma unroll
+            for (int i = 1; i < FM; ++i) xf[nxt][i] = xread(ntap, i, nkk);
+        }
+        post();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+        constexpr int NRD = FN + (xnext ? FM : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
+        constexpr bool HP = decltype(has_pre_c)::value && GN;
+        // one transform = 8 x (cvt, fma, mul, exp, add, rcp, mul) + 4 cvt_pk + 4 cndmask: 16 transcendental + ~52 other VALU
+        constexpr int NV = HP ? (52 + NMM - 1) / NMM : 0, NTR = HP ? (16 + NMM - 1) / NMM : 0;
+        static_assert(NRD <= NMM, "");
+#pragma unroll
+        for (int m = 0; m < NMM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (m - NRD < NPO) __builtin_amdgcn_sched_group_barrier(0x210, 1, 0);    // VMEM | DS write
+            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            if (NTR > 0) __builtin_amdgcn_sched_group_barrier(0x400, NTR, 0);
+        }
+        if constexpr (NPO > NMM - NRD) __builtin_amdgcn_sched_group_barrier(0x210, NPO - (NMM - NRD), 0);
+    };
+    auto none = []() __attribute__((always_inline)) {};
+
+    constexpr int DMA_OPS = BPW;
+    auto step = [&](int slab, auto tapc) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value;
+        // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
+        auto xf_q = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
+            if constexpr (tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
+        };
+        auto has_q = [&](int q) constexpr { return tap >= 3 && tap - 3 + q * LW < HPT; };
+        kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
+        kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
+        kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        W32_TR(1);
+        // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
+        //    its halo loads and its DMA batch.
+        wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        W32_TR(2);
+        lds_barrier();
+        W32_TR(3);
+        // -- window after P_s: next slab's halo chunks (hidden loads; from this slab again when there is no next one, the
+        //    count per window never changes), then -- beside the MFMAs of k16 step 3 -- the DMA of B[s+3] into the ring
+        //    slot step s just released and, at tap 8, the stores of the next slab's halo
+        {
+            const int hs = slab + 1 < nslab ? slab + 1 : slab;
+            if constexpr (tap < LW) {
+#pragma unroll
+                for (int j = tap; j < HPT; j += LW) halo_load(hs, j, true);
+            }
+        }
+        constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
+        kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
+              [&]() __attribute__((always_inline)) {
+                  if constexpr (tap == NTAPS - 1) {
+#pragma unroll
+                      for (int j = 0; j < HPT; ++j) halo_store(j);
+                  }
+#pragma unroll
+                  for (int q = 0; q < BPW; ++q) {
+                      if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
+                      else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+                  }
+              }, icw<NST + BPW>{});
+        __builtin_amdgcn_sched_barrier(0);
+        W32_TR(4);
+    };
+
+    // first fragments of the first step
+    W32_TR(0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[0][j] = wread(0, j, 0);
+
+    for (int slab = 0; slab < nslab; ++slab) {
+        load_ssr(slab + 1 < nslab ? slab + 1 : slab);     // constants of the slab whose halo is transformed during this one (from tap 3 on)
+        __builtin_amdgcn_sched_barrier(0);                // (its ds_reads must not take the fragment reads' slots in the pinned schedule)
+        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, tc); });
+        lds_barrier();                                    // the next slab's halo (stored after P_8) is complete
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+        W32_TR(5);
+    }
+    // the tail windows issued DMA and (unused) halo loads: everything must have landed before LDS / registers are reused
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+
+    // ---- epilogue: alpha, bias, residual, 16-byte stores, GroupNorm partial sums of what was stored.
+    // acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channel j*32 + 8*(r>>2) + 4*lh + (r&3).  Register quads
+    // (2m, 2m+1) are half-exchanged so lanes 0-31 own channels j*32+16m .. +7 and lanes 32-63 the next 8.
+    const T* __restrict__ res = (const T*)p.res;
+    const int ox = tx0 + l31;
+    const bool do_stats = p.gn_part != nullptr;
+    float gs[FN][4], gq[FN][4];                      // per (fragment, m, quad-in-chunk): this lane's sums over its FM pixels
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gs[j][q] = 0.f; gq[j][q] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cw = wn * WTN + j * 32 + m * 16 + lh * 8;          // channel inside the workgroup's tile
+            const int n = n0 + cw;
+            float bv[8];
+            if (bias_lds) {
+                const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + cw * 4), b1 = *(const f32x4*)(i2i_smem + BI0 + cw * 4 + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bv[r] = 0.f;
+            }
+            chunk_t rres[FM];
+            if (res) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int oy = ty0 + wm * FM + i;
+                    const bool ok = ox < p.wo && oy < p.ho && n < p.N;
+                    const int64_t mm = ((int64_t)img * p.ho + (ok ? oy : ty0)) * p.wo + (ok ? ox : tx0);
+                    rres[i] = *(const chunk_t*)(res + mm * p.ldr + (ok ? n : 0));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][8 * m + r], y = acc[i][j][8 * m + 4 + r];
+                    half_swap(x, y);                                       // wave-wide: before any lane drops out
+                    v[r] = x; v[4 + r] = y;
+                }
+                const int oy = ty0 + wm * FM + i;
+                if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
+                const int64_t mm = ((int64_t)img * p.ho + oy) * p.wo + ox;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r];
+                if (res) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][r]);
+                }
+                chunk_t o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                if (!W32_ABL(1)) *(chunk_t*)((T*)p.c + mm * p.ldc + n) = o;
+                if (do_stats) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float f = to_f32<T>(o[r]);
+                        gs[j][2 * m + (r >> 2)] += f; gq[j][2 * m + (r >> 2)] += f * f;
+                    }
+                }
+            }
+        }
+    }
+    // ---- GroupNorm partial sums: lane -> 32 pixels (shuffles) -> wave (LDS) -> workgroup -> one slot per group.
+    // Fixed reduction order: deterministic.  gs[j][q]: quad q = 2m + s covers channels j*32 + 16m + 8*lh + 4s .. +3.
+    if (do_stats) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mk = 1; mk < 32; mk <<= 1) { gs[j][q] += __shfl_xor(gs[j][q], mk); gq[j][q] += __shfl_xor(gq[j][q], mk); }
+        lds_barrier();                                   // every wave is done with its fragments, all DMA landed (vmcnt 0 above)
+        float* st = (float*)i2i_smem;                    // [NW][WTN/4 quads][2]
+        if (l31 == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int quad = (j * 32 + (q >> 1) * 16 + lh * 8 + (q & 1) * 4) >> 2;
+                    st[(wave * (WTN / 4) + quad) * 2 + 0] = gs[j][q];
+                    st[(wave * (WTN / 4) + quad) * 2 + 1] = gq[j][q];
+                }
+        }
+        lds_barrier();
+        const int groups = p.gn_part_groups, cpg = p.N / groups;
+        const int ng_tile = BN / cpg;
+        const int g = n0 / cpg + tid;
+        if (tid < ng_tile && g < groups) {
+            const int c0w = tid * cpg;
+            const int wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
+            float S = 0.f, Q = 0.f;
+            for (int wmm = 0; wmm < WM; ++wmm)
+                for (int q = q0; q < q0 + nq; ++q) {
+                    S += st[((wmm * WN + wnn) * (WTN / 4) + q) * 2 + 0];
+                    Q += st[((wmm * WN + wnn) * (WTN / 4) + q) * 2 + 1];
+                }
+            const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
+            float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
+            out[0] = S;
+            out[1] = Q;
+        }
+    }
+#ifdef I2I_TRACE
+    W32_TR(6);
+    if (p.ws && lane == 0) {
+        unsigned* o = (unsigned*)p.ws + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = tr_acc[k];
+    }
+#endif
+#undef W32_TR
+#undef W32_ABL
+}
+
+template <typename T, int TH, int BN, int WM, int WN>
+int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
+    const unsigned tiles = (unsigned)(((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN));
+    const bool gn = p.gn_ss != nullptr;
+    const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
+    if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
+    return i2i::check_launch("conv3x3_w32");
+}
+
+// tile ids 40..49 (i2i_igemm_params.tile): 40 = auto among the w32 configurations
+//   41: 8 x 32 px x 256 ch, 4 waves (128 px x 128 ch each, one per SIMD)      42: 16 x 32 px x 128 ch, 4 waves (128 x 128)
+// (8-wave forms of the same workgroup tiles -- 128 x 64 / 64 x 128 wave tiles at two waves per SIMD -- were built and
+// measured in round 3: within +-3 % of these without the GroupNorm prologue, out of registers with it;
+// profiles/r3_w32_ab_nogn.log.  Removed.)
+int w32_cfg(const i2i_igemm_params& p) {
+    int cfg = p.tile;
+    if (cfg == 0 || cfg == 40) cfg = (p.N % 256 == 0) ? 41 : 42;
+    return cfg;
+}
+void w32_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
+    if (cfg == 41) { *th = 8; *bn = 256; *wtn = 128; }
+    else { *th = 16; *bn = 128; *wtn = 128; }
+}
+
+template <typename T>
+int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
+    switch (w32_cfg(p)) {
+        case 41: return launch_w32<T, 8, 256, 2, 2>(p, s);
+        case 42: return launch_w32<T, 16, 128, 4, 1>(p, s);
+    }
+    return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3_w32: unknown tile config %d", p.tile);
+}
+
+}  // namespace
+
+namespace i2i {
+// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
+// counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
+// together with SiLU.  Not the sub-pixel form.
+bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
+    if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
+    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.subpix || p.out_f32 || p.act_out) return false;
+    if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
+    if (p.wo < W32_TW || p.ho < 8 || p.N < 128 || p.N % 8) return false;
+    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
+    if ((p.up_h || p.up_w) && p.ups != 1) return false;
+    if (p.ldc % 8 || (p.res && p.ldr % 8)) return false;
+    if (p.gn_ss && p.act != 1) return false;
+    if (!p.gn_ss && p.act) return false;
+    return true;
+}
+// tile == 0 routing: the wide tiles win on every VAE shape that fills the chip (profiles/r3_w32_ab_*.log: +20..24 % over
+// the halo conv with the GroupNorm prologue); channel counts that are not multiples of 128 would waste a third of a tile
+// and grids below ~7/8 of the CUs (UNet planes, batch 1) are better served by the 8x16 tiles of the halo conv.
+bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype) {
+    if (!conv3x3_w32_eligible(p, dtype) || p.N % 128) return false;
+    int th, bn, wtn;
+    w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
+    const long tiles = (long)p.nimg * ((p.ho + th - 1) / th) * ((p.wo + W32_TW - 1) / W32_TW) * ((p.N + bn - 1) / bn);
+    return tiles >= 224;
+}
+int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
+    if (!conv3x3_w32_eligible(p, dtype) || groups < 1 || p.N % groups) return 0;
+    const int cpg = p.N / groups;
+    int th, bn, wtn;
+    w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
+    if (cpg % 4 || wtn % cpg || bn % cpg) return 0;
+    return ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + th - 1) / th);
+}
+int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case I2I_BF16: return launch_w32_t<__bf16>(p, s);
+        case I2I_F16: return launch_w32_t<_Float16>(p, s);
+    }
+    return fail(I2I_ERR_BAD_ARG, "conv3x3_w32: bad dtype");
+}
+}  // namespace i2i

@@ -23,6 +23,10 @@ namespace i2i {
 bool conv3x3_halo_eligible(const i2i_igemm_params& p, int dtype);   // conv3x3.hip
 int conv3x3_halo(const i2i_igemm_params& p, int dtype, hipStream_t s);
 int conv3x3_halo_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
+bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype);    // conv3x3_w32.hip
+int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s);
+int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
+bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype);        // tile == 0: does the wide-tile kernel take this op?
 int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.hip
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
@@ -304,7 +308,10 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: act_out is implemented by the LDS-DMA igemm only (no GN prologue, aligned output, not a halo conv)");
     if (p.subpix && !i2i::conv3x3_halo_eligible(p, dtype))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need the halo conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
-    const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 49);
+    const bool w32_forced = p.tile >= 40 && p.tile <= 49;      // 32x32x16-MFMA wide-tile conv (conv3x3_w32.hip)
+    if (w32_forced && !i2i::conv3x3_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (w32 conv) not applicable", p.tile);
+    if (w32_forced || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32(p, dtype, s);
+    const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)
@@ -325,8 +332,21 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     i2i_igemm_params p = *pp;
     if (p.zcount < 1) p.zcount = 1;
     // mirrors the routing of i2i_igemm: halo conv when eligible and not forced elsewhere, else the LDS-DMA igemm
-    const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 49);
+    if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32_gn_parts(p, dtype, groups);
+    const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
     if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
     return 0;
+}
+
+extern "C" const char* i2i_igemm_route(const i2i_igemm_params* pp, int dtype) {
+    if (!pp) return "invalid";
+    i2i_igemm_params p = *pp;
+    if (p.zcount < 1) p.zcount = 1;
+    if (p.zh_count < 1) p.zh_count = 1;
+    if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return "conv3x3_w32_kernel";
+    const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
+    if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return p.subpix ? "conv3x3_halo_kernel<SUBPIX>" : "conv3x3_halo_kernel";
+    if ((p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) && i2i::igemm_dma_eligible(p, dtype)) return "igemm_dma_kernel";
+    return "igemm_kernel";
 }

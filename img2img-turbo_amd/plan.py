@@ -271,8 +271,9 @@ class ForwardPlan:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
         fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
-        kname = ("conv3x3_halo_kernel<SUBPIX>" if subpix else "conv3x3_halo_kernel") if halo else \
-                ("igemm_kernel (register-staged, GN prologue)" if fused else "igemm_dma_kernel")
+        kname = self.lib.igemm_route(op[1], self.dt)     # which kernel the C dispatcher picks (reporting only)
+        if fused and kname == "igemm_kernel":
+            kname = "igemm_kernel (register-staged, GN prologue)"
         if halo:
             self.halo_flops_real = getattr(self, "halo_flops_real", 0) + (fl * 4 // 9 if subpix else fl)
         self._add(op, label, fl, kernel=kname)

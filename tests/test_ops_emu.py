@@ -5,6 +5,8 @@ import pytest
 import torch
 
 import opcheck as oc
+from img2img_turbo_amd import _capi as K
+from img2img_turbo_amd import ops as O
 
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
@@ -355,3 +357,42 @@ def test_image_prep_options_match_the_reference_transforms(emu_lib):
     assert got.shape == (512, 512, 3) and np.array_equal(got, want)
     with pytest.raises(ValueError):
         apply_image_prep(t, "resize_286_randomcrop_256x256_hflip", emu_lib)
+
+
+# ---------------------------------------------------------------- wide-tile conv (conv3x3_w32.hip, tile ids 41, 42)
+W32_TILES = [41, 42]
+
+
+@pytest.mark.parametrize("cfg", W32_TILES)
+def test_w32_conv_every_tile_config(emu_lib, cfg):
+    """32x32x16-MFMA wide-tile conv: GroupNorm+SiLU staged in the MFMA shadow, residual, ragged tiles in both plane
+    directions, two slabs (the halo hand-over after P_8), ragged channel tile (N = 136 on BN = 128 / 256)."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=256, h=10, w=40, gn=True, act=1, groups=8, res=True, tile=cfg)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cin2=64, cout=136, h=17, w=33, tile=cfg, seed=3)
+
+
+def test_w32_conv_upsample_three_slabs_and_route(emu_lib):
+    """Nearest-2x gather while staging (non sub-pixel form), three slabs over a concat seam, explicit upsample size; the
+    route query names the kernel the dispatcher picks."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=128, h=8, w=16, ups=1, gn=True, act=1, groups=8, tile=42)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=9, w=32, res=True, alpha=0.5, tile=41)
+    x = torch.zeros(8, 128, 128, 128, dtype=torch.bfloat16)
+    w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16)
+    out = torch.zeros(8, 128, 128, 128, dtype=torch.bfloat16)
+    kw = dict(hin=128, win=128, ho=128, wo=128, ks=3, pad=1)
+    _, p = O.conv(x, w, out, nimg=8, **kw)
+    assert emu_lib.igemm_route(p, K.BF16) == "conv3x3_w32_kernel"          # 8 x 8 x 4 x 1 = 256 tiles of 16 x 32 x 128
+    _, p1 = O.conv(x[:1], w, out[:1], nimg=1, **kw)
+    assert emu_lib.igemm_route(p1, K.BF16) == "conv3x3_halo_kernel"         # batch 1: too few wide tiles to fill the chip
+    _, p2 = O.conv(x, w, out, nimg=8, tile=20, **kw)
+    assert emu_lib.igemm_route(p2, K.BF16) == "igemm_dma_kernel"
+    _, p3 = O.conv(x.float(), w.float(), out.float(), nimg=8, **kw)
+    assert emu_lib.igemm_route(p3, K.F32) == "conv3x3_halo_kernel"          # exact-f32 parity mode stays on the halo kernel
+
+
+@pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg):
+    """The epilogue's GroupNorm partial sums of the STORED output (one slot per tile and group), finished by gn_stats."""
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=64, groups=32, tile=cfg)      # cpg 8
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=20, w=40, groups=32, tile=cfg, res=False)   # cpg 4, ragged tiles
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=512, h=8, w=32, groups=32, tile=cfg)       # cpg 16

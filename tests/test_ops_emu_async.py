@@ -21,6 +21,17 @@ def test_halo_conv_waits(async_lib, cfg):
     oc.check_conv(async_lib, "cpu", torch.float32, n=1, cin=96, cout=40, h=9, w=17, tile=cfg)                                 # 3 slabs of 32
 
 
+@pytest.mark.parametrize("cfg", [41, 42])
+@pytest.mark.parametrize("order", [None, "0", "1", "7"])
+def test_w32_conv_waits_and_barriers(async_lib, cfg, order, monkeypatch):
+    """Wide-tile conv (conv3x3_w32.hip): counted vmcnt of the weight ring + hidden halo loads, and the single slab-end
+    barrier that publishes the halo stored after P_8, on the latest-completion memory model with run-ahead wave orders."""
+    if order is not None:
+        monkeypatch.setenv("I2I_EMU_ORDER", order)
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=192, cout=136, h=18, w=40, gn=True, act=1, res=True, tile=cfg)   # 3 slabs, ragged tiles
+    oc.check_conv_gn_part(async_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=16, w=32, groups=32, tile=cfg)
+
+
 def test_subpixel_and_partials_waits(async_lib):
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=72, h=12, w=20, ups=1, res=True, subpix=True)
     oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=64, h=16, w=16, groups=8, tile=13)
@@ -52,6 +63,8 @@ def test_model_is_sensitive_to_one_operation(async_lib, monkeypatch):
         oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, tile=25)
     with pytest.raises(AssertionError):
         oc.check_attention(async_lib, "cpu", torch.bfloat16, batch=1, heads=1, tq=64, tk=325)
+    with pytest.raises(AssertionError):
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=128, h=16, w=32, tile=42)
 
 
 @pytest.mark.slow
