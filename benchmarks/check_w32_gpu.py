@@ -21,6 +21,6 @@ for t in tiles:
             e.append(oc.check_conv(lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=40, w=72, gn=True, act=1, groups=8, res=True, tile=t, seed=rep))
             e.append(oc.check_conv(lib, "cuda", torch.float16, n=1, cin=64, cin2=128, cout=136, h=33, w=65, gn=True, act=1, groups=8, tile=t, seed=rep))
         e.append(oc.check_conv(lib, "cuda", torch.bfloat16, n=3, cin=256, cout=384, h=24, w=64, tile=t, seed=rep))
-        e.append(oc.check_conv(lib, "cuda", torch.float16, n=1, cin=64, cout=128, h=16, w=32, ups=1, res=True, tile=t, seed=rep))
+        e.append(oc.check_conv(lib, "cuda", torch.float16, n=9, cin=64, cout=128, h=64, w=96, res=True, tile=t, seed=rep))
         print("tile", t, "rep", rep, " ".join("%.2e" % x for x in e), flush=True)
 print("W32 GPU PARITY OK")

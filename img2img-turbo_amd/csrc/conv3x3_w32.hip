@@ -1,9 +1,9 @@
 // 3x3 stride-1 pad-1 implicit-GEMM convolution, "wide" operating point for gfx950: 32x32x16 MFMA, wave tiles of
-// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file) at ONE wave per SIMD,
-// or 128 x 64 / 64 x 128 at two.  Same replaced reference ops as conv3x3.hip (F.conv2d of diffusers ResnetBlock2D /
-// Upsample2D with the preceding F.group_norm + F.silu, torch.cat and nearest-2x folded into the operand staging,
-// bias / residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode
-// and planes narrower than 32 stay on conv3x3_halo_kernel).
+// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file), ONE wave per SIMD, one
+// persistent workgroup per CU walking a stream of tiles.  Same replaced reference ops as conv3x3.hip (F.conv2d of
+// diffusers ResnetBlock2D with the preceding F.group_norm + F.silu and torch.cat folded into the operand staging, bias /
+// residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode, planes
+// narrower than 32, upsampling gathers and grids that cannot fill the chip stay on conv3x3_halo_kernel).
 //
 // Why a second operating point: the 64x64 wave tile on 16x16x32 MFMAs at two waves per SIMD is
 // issue bound -- per 32 MFMAs (512 matrix cycles) a wave issues 16 ds_read_b128, its DMA share, waits and a barrier.
@@ -11,20 +11,26 @@
 // the MFMA instructions per FLOP, and with 8 issue slots per MFMA and nobody else on the SIMD the GroupNorm+SiLU of
 // the NEXT slab's halo runs in the MFMA shadow instead of in a serial hand-over.
 //
-// Workgroup = TH x 32 output pixels of one image x BN channels; WM x WN waves, wave = FM tile rows (one 32-pixel
+// Workgroup tile = TH x 32 output pixels of one image x BN channels; WM x WN waves, wave = FM tile rows (one 32-pixel
 // fragment each) x FN 32-channel fragments.  K loop = (64-channel slab) x (9 taps) x (4 k16 steps):
-//   * pixels: the (TH+2) x 34 halo of a slab is staged once (16-byte loads hidden from the compiler's waitcnt
-//     bookkeeping -> GN affine + SiLU in registers, spread over the taps -> ds_write_b128 at the slab hand-over);
-//     tap (dy,dx) reads 32 consecutive 128-byte LDS rows starting at (row+dy)*34+dx, lanes 0-31 the even chunk of the
-//     k16 step and lanes 32-63 the odd one.  XOR swizzle chunk ^ ((row>>1)&7): conflict-free for every start row
-//     (tools/lds_bank_model.py).
+//   * pixels: the (TH+2) x 34 halo of a slab lives in FOUR LDS planes, one per k16 step (rows of 32 bytes, chunk XOR
+//     bit 3 of the row): a fragment read (32 consecutive rows at ANY start, lanes 0-31 chunk 0, lanes 32-63 chunk 1)
+//     is conflict-free and the k16 step is an immediate offset (tools/lds_bank_model.py).  The NEXT slab's halo is
+//     loaded by 16-byte loads hidden from the compiler's waitcnt bookkeeping in the windows of taps 0..5, transformed
+//     (GN affine + SiLU) in registers beside the MFMAs of taps 3..8 and stored after the slab's last step barrier.
 //   * weights [N][9*Cin]: LDS-DMA into a 3-deep ring of [BN][64] slabs, swizzle carried by the per-lane source
 //     address, issued right after the step barrier that frees the slot and waited for two steps later with a counted
-//     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free (tail steps re-fetch valid
-//     weights that nobody reads), so the counts are exact.
-//   * ONE s_barrier per step, between k16 steps 2 and 3; fragment reads run one k16 step ahead of their MFMAs.
-//   * MFMA operands swapped (A = weight rows) so an accumulator lane owns 4 consecutive channels of one pixel per
-//     register quad; quads are half-exchanged with v_permlane32_swap so every lane stores 16 bytes.
+//     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free, so the counts are exact.
+//   * ONE s_barrier per step (between k16 steps 2 and 3) + one per slab; fragment reads run one k16 step ahead.
+//   * the slab stream is CONTINUOUS ACROSS TILES: during a tile's last slab the staged halo, the GroupNorm constants
+//     and the ring's tail batches are those of the workgroup's next tile, so a tile costs its MFMAs + its epilogue.
+//     With one workgroup per CU nothing else would cover a prologue (measured 20 % of a 2-slab tile, profiles/r3a_*).
+//   * epilogue: accumulators (lane = 4 consecutive channels of one pixel per register quad, quads half-exchanged with
+//     v_permlane32_swap) -> alpha, bias, residual -> 16-bit -> a wave-private LDS staging block -> read back as whole
+//     256-byte pixel rows -> full-line global stores (the accumulator layout would store 32-byte pieces of 32 lines per
+//     instruction: store-issue bound, 24 % of a 2-slab tile) and the GroupNorm partial sums of the stored values.
+#include <stdlib.h>
+
 #include "i2i_dev.h"
 #include "launch.h"
 
@@ -45,23 +51,60 @@ template <int N, class F> __device__ __forceinline__ void static_for_w(F&& f) {
 
 __device__ __forceinline__ int swz3(int row) { return (row >> 1) & 7; }
 
-constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
+// All lanes of the wave have executed everything before this point (LDS traffic of one wave is processed in issue
+// order on the hardware; the CPU emulator runs lanes as independent fibers and needs the rendezvous).
+#ifdef I2I_EMU
+__device__ __forceinline__ void wave_sync() { (void)__shfl_xor(0, 1); }
+#else
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#endif
+
+// Re-defines a lane-constant for the optimiser at this point: without it LICM hoists every address / index derived from
+// it out of the tile and slab loops (dozens of registers live across the whole kernel -> spills, and a spill reload's
+// compiler-inserted vmcnt(0) would also break the hand-counted waits).  Emits no instruction.
+#ifdef I2I_EMU
+template <typename V> __device__ __forceinline__ void opaque(V&) {}
+#else
+template <typename V> __device__ __forceinline__ void opaque(V& x) { asm volatile("" : "+v"(x)); }
+#endif
+
+#ifdef I2I_EMU
+__device__ __forceinline__ int mul24(int a, int b) { return a * b; }
+#else
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }       // v_mul_i32_i24: full rate (operands < 2^23)
+#endif
+
+constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3;
 // bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
 constexpr int w32_plane(int th) { return (((th + 2) * (W32_TW + 2) * 32 + 127) / 128) * 128 + 32; }
+// pixels per epilogue staging round per wave (a pixel = the wave's 128 channels = 256 bytes): what the LDS left beside
+// the halo planes and the weight ring allows
+constexpr int w32_stage_px(int bn) { return bn <= 128 ? 32 : 16; }
+constexpr size_t w32_lds_bytes(int th, int bn, int nw) {
+    return (size_t)4 * w32_plane(th) + 1024 + (size_t)W32_RING * bn * 128 + 512 + (size_t)bn * 4 + (size_t)nw * w32_stage_px(bn) * 256;
+}
+
+// Tile stream of a launch (host side fills it): workgroup b serves channel tile (b>>3) % ntn and, inside the contiguous
+// run of spatial tiles of XCD b & 7 (workgroup b runs on XCD b % 8: neighbouring tiles meet in one L2), the tiles
+// lg, lg + lgroups, ... with lg = (b>>3) / ntn.
+struct w32_sched { int ntn, lgroups, tiles_x, tiles_y, nsp; };
 
 // GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
 template <typename T, int TH, int BN, int WM, int WN, bool GN>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const w32_sched sc) {
     constexpr int TW = W32_TW, CK = W32_CK, RING = W32_RING, NTAPS = 9;
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int HW2 = TW + 2, HALO = (TH + 2) * HW2;
     static_assert(TH % WM == 0 && BN % (32 * WN) == 0, "");
     constexpr int FM = TH / WM, WTN = BN / WN, FN = WTN / 32;
+    static_assert(WTN == 128, "the epilogue stages 256-byte pixel rows per wave");
     constexpr int HPT = (HALO * 8 + NT - 1) / NT;      // halo chunks per thread per slab
+    constexpr int PPJ = NT / 8;                        // halo pixels covered per chunk index j
     constexpr int NPIECE = BN / 8;                     // 1-KiB LDS-DMA pieces per weight slab
     static_assert(NPIECE % NW == 0, "every wave issues the same number of DMA pieces");
     constexpr int BPW = NPIECE / NW;
     constexpr int PLANE = w32_plane(TH);
+    constexpr int SPX = w32_stage_px(BN), NRND = 32 / SPX;       // staging rounds per tile row
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit dtypes only");
 
@@ -72,8 +115,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     const int kc = tid & 7;
     // Measurement hook (csrc/build.py --tag trace --defs=-DI2I_TRACE=1; never in the product build): every wave sums the
     // shader cycles (s_memtime) it spends per pipeline segment and writes them to p.ws [workgroup][wave][16]:
-    // 0 prologue, 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3, 5 slab-end barrier + first
-    // reads, 6 epilogue.  p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 8 no MFMAs.
+    // 0 prologue (once per workgroup), 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3,
+    // 5 slab-end wait + barrier + first reads, 6 epilogue, 7 tile set-up (next tile decode, accumulator reset).
+    // p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 8 no MFMAs.
 #ifdef I2I_TRACE
     unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned tr_t = (unsigned)__builtin_amdgcn_s_memtime();
@@ -84,65 +128,73 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #define W32_ABL(bit) false
 #endif
 
-    // ---- XCD-aware tile id (bijective for any grid): every XCD gets one contiguous run of tiles, channel tiles fastest
-    int bid;
+    // ---- this workgroup's tile stream
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int tn = lb % sc.ntn, lg = lb / sc.ntn;
+    int s_cur, cnt;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int q = sc.nsp >> 3, r = sc.nsp & 7;
+        s_cur = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lg;
+        cnt = q + (xcd < r ? 1 : 0);
     }
-    const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
-    const int ntn = (p.N + BN - 1) / BN;
-    const int tn = bid % ntn; bid /= ntn;
-    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
-    const int ty0 = (bid % tiles_y) * TH;
-    const int img = bid / tiles_y;
+    if (lg >= cnt) return;                             // fewer tiles than workgroups (uniform)
     const int n0 = tn * BN;
 
-    const T* __restrict__ a0 = (const T*)p.a0;
-    const T* __restrict__ a1 = (const T*)p.a1;
     const T* __restrict__ bw = (const T*)p.b;
     const int cin = p.c0 + p.c1;
-    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
+    const int nslab = cin / CK;
+    const int64_t img_stride0 = (int64_t)p.hin * p.win * p.lda0 * (int)sizeof(T), img_stride1 = (int64_t)p.hin * p.win * p.lda1 * (int)sizeof(T);
 
-    // LDS map.  Halo: FOUR planes, one per k16 step (channels 16*kk .. +15 of the slab), rows of 32 bytes = 2 chunks,
-    // chunk h of row r at physical chunk h ^ ((r>>3)&1): a fragment read (32 consecutive rows, lanes 0-31 chunk 0,
-    // lanes 32-63 chunk 1) is conflict-free for every start row, and the k16 step is a pure immediate offset.  PLANE
-    // = 32 (mod 128) so that the eight chunks of one pixel (8 consecutive lanes of a ds_write_b128) hit distinct banks.
-    // | 4 planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring | GN consts | bias |
+    // LDS map: | 4 halo planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring |
+    //          | GroupNorm (scale, shift) of the slab being staged, 512 B | bias of the channel tile | staging, per wave |
     constexpr int HS0 = 0;
     constexpr int DUM0 = 4 * PLANE;
     constexpr int BS0 = DUM0 + 1024;
-    constexpr int SS0 = BS0 + RING * BN * 128;          // [cin][2] fp32
-    const int BI0 = SS0 + (GN ? cin * 8 : 0);           // [BN] fp32
+    constexpr int SS0 = BS0 + RING * BN * 128;
+    constexpr int BI0 = SS0 + 512;
+    constexpr int STG0 = BI0 + BN * 4;
     char* Bs = i2i_smem + BS0;
     const bool bias_lds = p.bias_mode == 1;
 
-    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
-    // hpix = pixel index inside image `img` (0 for zero padding, flagged in padmask: conv pads the ACTIVATED tensor).
-    unsigned hpix[HPT], padmask = 0;
+    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel hp = v>>3 = (hy, hx), chunk kc = tid&7.
+    // hrel[j] = hy*win + hx is tile independent; the pixel index inside the image is pb + hrel[j] with the tile's
+    // pb = (ty0-1)*win + tx0-1 -- unless the pixel is zero padding (bit j of the tile's pad mask: conv pads the
+    // ACTIVATED tensor, so padding lanes load pixel 0 and the transform replaces them by zeros).
+    // One base + a per-lane wrap mask instead of HPT registers: hp advances by PPJ pixels per j; bit j of `wrapm` says
+    // that step j -> j+1 crosses into the next halo row, which adds (win - 34) on top of the PPJ.
+    int hp0 = tid >> 3, hy0 = hp0 / HW2, hx0 = hp0 - hy0 * HW2;
+    static_assert(PPJ < HW2 || PPJ % HW2 < HW2, "");
+    int hrel0 = hy0 * p.win + hx0;
+    unsigned wrapm = 0;
+    {
+        int hx = hx0;
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) {
-        const int hp = (tid >> 3) + j * (NT / 8);
-        unsigned pix = 0;
-        bool pad = true;
-        if (hp < HALO) {
-            const int hy = hp / HW2, hx = hp - hy * HW2;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
-            if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up) {
-                pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
-                pad = false;
-            }
+        for (int j = 0; j + 1 < HPT; ++j) {
+            hx += PPJ % HW2;
+            if (hx >= HW2) { hx -= HW2; wrapm |= 1u << j; }
         }
-        hpix[j] = pix;
-        padmask |= (pad ? 1u : 0u) << j;
     }
-    const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
-    const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
-    // LDS store address of chunk j: st_off + j * (NT/8)*32 (row bit 3 does not change with j); the last chunk row
-    // may run past the halo: those lanes store into the dummy block
-    const int st_off = HS0 + (kc >> 1) * PLANE + (tid >> 3) * 32 + (((kc & 1) ^ (((tid >> 3) >> 3) & 1)) << 4);
-    const int st_last = ((tid >> 3) + (HPT - 1) * (NT / 8) < HALO) ? st_off + (HPT - 1) * (NT / 8) * 32 : DUM0 + lane * 16;
+    const int row_skip = p.win - HW2;
+    auto hrel = [&](int j) __attribute__((always_inline)) -> int {   // hy_j*win + hx_j
+        return hrel0 + j * (PPJ % HW2) + (j * (PPJ / HW2)) * p.win + mul24(__builtin_popcount(wrapm & ((1u << j) - 1u)), row_skip);
+    };
+    auto pad_of = [&](int ty0, int tx0) __attribute__((always_inline)) -> unsigned {
+        unsigned m = 0;
+        int hy = hy0, hx = hx0;
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            const bool in = hp0 + j * PPJ < HALO && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+            m |= (in ? 0u : 1u) << j;
+            hx += PPJ % HW2; hy += PPJ / HW2;
+            if (hx >= HW2) { hx -= HW2; ++hy; }
+        }
+        return m;
+    };
+    // LDS store address of chunk j: st_off + j*PPJ*32 (row bit 3 does not change with j); the last chunk row may run
+    // past the halo: those lanes store into the dummy block
+    int st_off = HS0 + (kc >> 1) * PLANE + hp0 * 32 + (((kc & 1) ^ ((hp0 >> 3) & 1)) << 4);
+    int st_last = (hp0 + (HPT - 1) * PPJ < HALO) ? st_off + (HPT - 1) * PPJ * 32 : DUM0 + lane * 16;
 
     // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3), physical
     // chunk lane&7 = source chunk (lane&7) ^ swz3(row).  Rows past N are clamped (their columns are never stored).
@@ -154,31 +206,50 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         n = n < p.N ? n : p.N - 1;
         b_voff[q] = (unsigned)(n * p.ldb + (((lane & 7) ^ swz3(row)) * 8)) * (unsigned)sizeof(T);
     }
-    const int nslab = cin / CK;
-    // step index (slab*9 + tap) may run past the last one at the tail: those fetch slab 0 again (valid, never read)
+    // slab index past the tile's last = the next tile's slabs (same channel tile: same weights)
     auto b_dma_q = [&](int slab, int tap, int buf, int q) __attribute__((always_inline)) {
-        const int sl = slab < nslab ? slab : 0;
+        const int sl = slab < nslab ? slab : slab - nslab;
         const char* src = (const char*)(bw + (tap * cin + sl * CK));
         glds16_sv(src, b_voff[q], Bs + buf * BN * 128 + (wave + q * NW) * 1024);
     };
 
-    chunk_t rh[HPT];
-    // One 16-byte load per call, always and branch-free (padding lanes read pixel 0 and are zeroed by the transform)
-    auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
+    // ---- the slab being STAGED (next slab of this tile, or slab 0 of the next tile): wave-uniform descriptor
+    const char* sg_base = nullptr;                      // source pointer of its first channel, image included
+    unsigned sg_ld = 0;                                 // pixel stride in bytes
+    int sg_pb = 0;                                      // pixel base (ty0-1)*win + tx0-1
+    unsigned sg_pad = 0;                                // zero-padding mask of this thread's chunks
+    const float* sg_ss = nullptr;                       // its 64 (scale, shift) pairs
+    auto set_stage = [&](int img, int ty0, int tx0, unsigned pad, int slab) __attribute__((always_inline)) {
         const int ci = slab * CK;
-        const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
-        const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
-        const unsigned voff = hpix[j] * ldb + (unsigned)kc * 16u;
-        if (hidden) gload16_uncounted(rh[j], base, voff);
-        else rh[j] = *(const chunk_t*)(base + voff);
+        sg_base = ci < p.c0 ? (const char*)p.a0 + img * img_stride0 + ci * (int)sizeof(T)
+                            : (const char*)p.a1 + img * img_stride1 + (ci - p.c0) * (int)sizeof(T);
+        sg_ld = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
+        sg_pb = (ty0 - 1) * p.win + tx0 - 1;
+        sg_pad = pad;
+        if constexpr (GN) sg_ss = p.gn_ss + ((int64_t)img * cin + ci) * 2;
+    };
+
+    chunk_t rh[HPT];
+    // One 16-byte load per call, always and branch-free
+    auto halo_load = [&](int j, bool hidden) __attribute__((always_inline)) {
+        const unsigned pix = (unsigned)(sg_pb + hrel(j)) & (((sg_pad >> j) & 1u) - 1u);      // padding lanes: pixel 0, branch-free
+        const unsigned voff = pix * sg_ld + (unsigned)kc * 16u;
+        if (hidden) gload16_uncounted(rh[j], sg_base, voff);
+        else rh[j] = *(const chunk_t*)(sg_base + voff);
+    };
+    auto ss_dma = [&]() __attribute__((always_inline)) {            // every wave writes the same 512 bytes: equal VMEM counts
+        if constexpr (GN) {
+            if (lane < CK / 2) glds16(sg_ss + lane * 4, i2i_smem + SS0);
+            else note_vmem(1);     // vmcnt counts the instruction for the whole wave (the emulator's queues are per lane)
+        }
     };
     // GroupNorm affine + SiLU of one parked chunk, in place; padding chunks become exact zeros
-    float ssr[16];                                      // (scale, shift) of this thread's 8 channels, slab being staged
-    auto load_ssr = [&](int slab) __attribute__((always_inline)) {
+    float ssr[16];                                      // (scale, shift) of this thread's 8 channels of the staged slab
+    auto load_ssr = [&]() __attribute__((always_inline)) {
         if constexpr (GN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + (slab * CK + kc * 8) * 8 + q * 16);
+                const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + kc * 64 + q * 16);
                 ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
             }
         }
@@ -189,29 +260,38 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #pragma unroll
             for (int e = 0; e < 8; ++e) c[e] = from_f32<T>(silu_f(__builtin_fmaf(to_f32<T>(c[e]), ssr[2 * e], ssr[2 * e + 1])));
         }
-        rh[j] = ((padmask >> j) & 1u) ? zero_chunk<T>() : c;
+        rh[j] = ((sg_pad >> j) & 1u) ? zero_chunk<T>() : c;
     };
     auto halo_store = [&](int j) __attribute__((always_inline)) {
-        *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * (NT / 8) * 32)) = rh[j];
+        *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * PPJ * 32)) = rh[j];
     };
 
     f32x16 acc[FM][FN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
 
-    // ---- prologue: weights of steps 0..2, GN constants of every input channel, bias, halo of slab 0
+    // ---- tile coordinates
+    const int tiles_per_img = sc.tiles_x * sc.tiles_y;
+    auto decode = [&](int s, int& img, int& ty0, int& tx0) __attribute__((always_inline)) {
+        img = s / tiles_per_img;
+        const int t = s - img * tiles_per_img, ty = t / sc.tiles_x;
+        ty0 = ty * TH;
+        tx0 = (t - ty * sc.tiles_x) * TW;
+    };
+    int c_img, c_ty0, c_tx0;
+    decode(s_cur, c_img, c_ty0, c_tx0);
+
+    // ---- prologue (once per workgroup): weights of steps 0..2, bias, and the first tile's slab 0 synchronously
 #pragma unroll
     for (int t = 0; t < RING; ++t)
 #pragma unroll
         for (int q = 0; q < BPW; ++q) b_dma_q(0, t, t, q);
-    if constexpr (GN) {
-        for (int pc = wave; pc * 128 < cin; pc += NW)      // 1 KiB = (scale, shift) of 128 channels per piece
-            if (pc * 128 + lane * 2 < cin) glds16(p.gn_ss + ((int64_t)img * cin + pc * 128 + lane * 2) * 2, i2i_smem + SS0 + pc * 1024);
-    }
     if (bias_lds && wave == NW - 1) {
 #pragma unroll
         for (int q = 0; q < (BN + 255) / 256; ++q) {
@@ -222,41 +302,47 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             }
         }
     }
+    set_stage(c_img, c_ty0, c_tx0, pad_of(c_ty0, c_tx0), 0);
+    ss_dma();
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
+    for (int j = 0; j < HPT; ++j) halo_load(j, false);
     wait_vmcnt<0>();
     lds_barrier();
-    load_ssr(0);
+    load_ssr();
 #pragma unroll
     for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
     lds_barrier();
 
     // ---- per-lane LDS read bases.  Pixel fragment row = u + c with u = wm*FM*34 + l31 (lane) and c = (i+dy)*34 + dx
-    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only: 16 bases x_off[c & 15]; the row part of c and
-    // the k16 plane enter as the immediate c*32 + kk*PLANE.
-    int x_off[16];
-    {
-        const int u = wm * FM * HW2 + l31;
+    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only; the row part of c and the k16 plane enter as the
+    // immediate c*32 + kk*PLANE.
+    // (u + c) mod 16 >= 8 for c & 15 = m is bit m of `xm`: base + an XOR of 16 (3 VALU per read instead of 16 registers).
+    const int xu = wm * FM * HW2 + l31;
+    int x_base = HS0 + xu * 32 + (lh << 4);
+    unsigned xm16 = 0;                                  // bit (m + 4) = bit 3 of (xu + m)
 #pragma unroll
-        for (int m = 0; m < 16; ++m) x_off[m] = HS0 + u * 32 + ((lh ^ (((u + m) >> 3) & 1)) << 4);
-    }
-    const int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
+    for (int m = 0; m < 16; ++m) xm16 |= (unsigned)(((xu + m) >> 3) & 1) << (m + 4);
+    int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
 
     chunk_t xf[2][FM], wf[2][FN];
     auto xread = [&](int tap, int i, int kk) __attribute__((always_inline)) -> chunk_t {
         const int c = (i + tap / 3) * HW2 + tap % 3;
-        return *(const chunk_t*)(i2i_smem + x_off[c & 15] + (kk * PLANE + c * 32));
+        return *(const chunk_t*)(i2i_smem + (x_base ^ ((xm16 >> (c & 15)) & 16u)) + (kk * PLANE + c * 32));
     };
     auto wread = [&](int buf, int j, int kk) __attribute__((always_inline)) -> chunk_t {
         return *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + buf * BN * 128 + j * 4096);
     };
 
-    // Halo chunks of the NEXT slab: loaded in the windows of taps 0..5 (chunks t, t+6, ...: a load issued after P_t is
+    // Halo chunks of the staged slab: loaded in the windows of taps 0..5 (chunks t, t+6, ...: a load issued after P_t is
     // covered by the counted wait of P_{t+2}), transformed during step t+3 (q-th chunk of the window beside k16 step q),
     // stored after P_8 -- when every fragment read of the current halo has completed -- in the shadow of the slab's
-    // last 16 MFMAs.  ONE extra barrier per slab, no serial hand-over.
+    // last 16 MFMAs.  The GroupNorm constants of the staged slab ride in window 0 and are read after P_2.
     constexpr int LW = 6;
-    auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c; return c; };
+    auto nh = [](int t) constexpr {                    // VMEM operations of window t besides the DMA batch
+        int c = 0;
+        for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c;
+        return c + ((GN && t == 0) ? 1 : 0);
+    };
     static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
 
     // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
@@ -300,7 +386,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto none = []() __attribute__((always_inline)) {};
 
     constexpr int DMA_OPS = BPW;
-    auto step = [&](int slab, auto tapc) __attribute__((always_inline)) {
+    // `settled`: first slab of a tile -- everything issued before it was waited for at the tile border (vmcnt 0), and
+    // the epilogue's stores sit in the queue: steps 0 and 1 need nothing new and must not wait behind those stores.
+    auto step = [&](int slab, bool settled, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
         auto xf_q = [&](auto qc) __attribute__((always_inline)) {
@@ -314,21 +402,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         __builtin_amdgcn_sched_barrier(0);
         W32_TR(1);
         // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
-        //    its halo loads and its DMA batch.
-        wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        //    its halo loads (+ constants) and its DMA batch.
+        if constexpr (tap < 2) {
+            if (!settled) wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        } else {
+            wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        }
         W32_TR(2);
         lds_barrier();
         W32_TR(3);
-        // -- window after P_s: next slab's halo chunks (hidden loads; from this slab again when there is no next one, the
-        //    count per window never changes), then -- beside the MFMAs of k16 step 3 -- the DMA of B[s+3] into the ring
-        //    slot step s just released and, at tap 8, the stores of the next slab's halo
-        {
-            const int hs = slab + 1 < nslab ? slab + 1 : slab;
-            if constexpr (tap < LW) {
+        // -- window after P_s: the staged slab's halo chunks (hidden loads) and constants, then -- beside the MFMAs of
+        //    k16 step 3 -- the DMA of B[s+3] into the ring slot step s just released and, at tap 8, the halo stores
+        if constexpr (tap < LW) {
 #pragma unroll
-                for (int j = tap; j < HPT; j += LW) halo_load(hs, j, true);
-            }
+            for (int j = tap; j < HPT; j += LW) halo_load(j, true);
         }
+        if constexpr (tap == 0) ss_dma();
+        if constexpr (tap == 2) load_ssr();               // constants published by P_2; the previous ones died with tap 8
         constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
         kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
               [&]() __attribute__((always_inline)) {
@@ -346,6 +436,133 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         W32_TR(4);
     };
 
+    // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channel j*32 + 8*(r>>2) + 4*lh +
+    // (r&3); register quads (2m, 2m+1) are half-exchanged so lanes 0-31 own channels j*32+16m .. +7 and lanes 32-63 the
+    // next 8 = 16-byte chunk j*4 + 2m + lh of the pixel's 256-byte row.  Staging image (wave private): pixel row of 256
+    // bytes, chunk c at c ^ (pixel & 15) (conflict-free for the column-of-pixels writes and the row reads).
+    const T* __restrict__ res = (const T*)p.res;
+    const bool do_stats = p.gn_part != nullptr;
+    char* const stg = i2i_smem + STG0 + wave * (SPX * 256);
+    auto epilogue = [&](int img, int ty0, int tx0) __attribute__((always_inline)) {
+        const int ox = tx0 + l31;
+        const int c16 = lane & 15, p4 = lane >> 4;            // read-back role: chunk c16 of pixels p4, p4+4, ...
+        const int nrb = n0 + wn * WTN + c16 * 8;              // first channel of the read-back chunk
+        float gs[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);                // one tile row at a time: nothing of the next row (its residual loads,
+                                                              // its accumulator reads) may be hoisted into this one's register budget
+            const int oy = ty0 + wm * FM + i;
+            chunk_t rres[FN * 2];
+            if (res) {                                         // residual in the accumulator layout, all loads in flight together
+#pragma unroll
+                for (int jm = 0; jm < FN * 2; ++jm) {
+                    const int n = n0 + wn * WTN + jm * 16 + lh * 8;
+                    const bool ok = ox < p.wo && oy < p.ho && n < p.N;
+                    const int64_t mm = ((int64_t)img * p.ho + (ok ? oy : 0)) * p.wo + (ok ? ox : 0);
+                    rres[jm] = *(const chunk_t*)(res + mm * p.ldr + (ok ? n : 0));
+                }
+            }
+            auto make_o = [&](int jm) __attribute__((always_inline)) -> chunk_t {
+                const int j = jm >> 1, m = jm & 1;
+                const int cw = wn * WTN + jm * 16 + lh * 8;   // channel inside the workgroup's tile
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][8 * m + r], y = acc[i][j][8 * m + 4 + r];
+                    half_swap(x, y);
+                    v[r] = x; v[4 + r] = y;
+                }
+                if (bias_lds) {
+                    const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + cw * 4), b1 = *(const f32x4*)(i2i_smem + BI0 + cw * 4 + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = p.alpha * v[r] + b0[r]; v[4 + r] = p.alpha * v[4 + r] + b1[r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r];
+                }
+                if (res) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[jm][r]);
+                }
+                chunk_t o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                return o;
+            };
+            chunk_t o[NRND == 1 ? 1 : FN * 2];
+            if constexpr (NRND > 1) {
+#pragma unroll
+                for (int jm = 0; jm < FN * 2; ++jm) o[jm] = make_o(jm);
+            }
+#pragma unroll
+            for (int rd = 0; rd < NRND; ++rd) {
+                // stage SPX pixels x 256 bytes: the lanes whose pixel column falls into this round write their 8 chunks
+                wave_sync();                                   // (emulator) the previous round's reads are done
+                if constexpr (NRND == 1) {
+#pragma unroll
+                    for (int jm = 0; jm < FN * 2; ++jm)
+                        *(chunk_t*)(stg + l31 * 256 + (((jm * 2 + lh) ^ (l31 & 15)) << 4)) = make_o(jm);
+                } else {
+                    if ((l31 / SPX) == rd) {
+                        const int px = l31 % SPX;
+#pragma unroll
+                        for (int jm = 0; jm < FN * 2; ++jm)
+                            *(chunk_t*)(stg + px * 256 + (((jm * 2 + lh) ^ (px & 15)) << 4)) = o[jm];
+                    }
+                }
+                wave_sync();                                   // (emulator) every lane's chunks are staged
+#pragma unroll
+                for (int k = 0; k < SPX / 4; ++k) {
+                    const int px = k * 4 + p4;
+                    const chunk_t c = *(const chunk_t*)(stg + px * 256 + ((c16 ^ (px & 15)) << 4));
+                    const int sx = tx0 + rd * SPX + px;
+                    if (sx < p.wo && oy < p.ho && nrb < p.N) {
+                        if (!W32_ABL(1)) *(chunk_t*)((T*)p.c + (((int64_t)img * p.ho + oy) * p.wo + sx) * p.ldc + nrb) = c;
+                        if (do_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(c[e]); gs[e] += f; gq[e] += f * f; }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- GroupNorm partial sums of the stored values: lane -> the 4 lanes sharing a chunk (2 shuffles) -> wave (its
+        // staging block) -> workgroup -> one slot per (tile, group).  Fixed order: deterministic.
+        if (do_stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gs[e] += __shfl_xor(gs[e], 16); gs[e] += __shfl_xor(gs[e], 32);
+                gq[e] += __shfl_xor(gq[e], 16); gq[e] += __shfl_xor(gq[e], 32);
+            }
+            wave_sync();
+            float* st = (float*)stg;                         // [128 channels][2]
+            if (p4 == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st[(c16 * 8 + e) * 2 + 0] = gs[e]; st[(c16 * 8 + e) * 2 + 1] = gq[e]; }
+            }
+            lds_barrier();
+            const int groups = p.gn_part_groups, cpg = p.N / groups;
+            const int ng_tile = BN / cpg;
+            const int g = n0 / cpg + tid;
+            if (tid < ng_tile && g < groups) {
+                const int c0w = tid * cpg, wnn = c0w / WTN, cl = c0w - wnn * WTN;
+                float S = 0.f, Q = 0.f;
+                for (int wmm = 0; wmm < WM; ++wmm) {
+                    const float* sw = (const float*)(i2i_smem + STG0 + (wmm * WN + wnn) * (SPX * 256));
+                    for (int c = cl; c < cl + cpg; ++c) { S += sw[c * 2]; Q += sw[c * 2 + 1]; }
+                }
+                const int tile_in_img = (ty0 / TH) * sc.tiles_x + tx0 / TW;
+                float* out = p.gn_part + (((int64_t)img * tiles_per_img + tile_in_img) * groups + g) * 2;
+                out[0] = S;
+                out[1] = Q;
+            }
+            lds_barrier();                                   // the staging blocks are free again
+        }
+    };
+
     // first fragments of the first step
     W32_TR(0);
 #pragma unroll
@@ -353,130 +570,43 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #pragma unroll
     for (int j = 0; j < FN; ++j) wf[0][j] = wread(0, j, 0);
 
-    for (int slab = 0; slab < nslab; ++slab) {
-        load_ssr(slab + 1 < nslab ? slab + 1 : slab);     // constants of the slab whose halo is transformed during this one (from tap 3 on)
-        __builtin_amdgcn_sched_barrier(0);                // (its ds_reads must not take the fragment reads' slots in the pinned schedule)
-        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, tc); });
-        lds_barrier();                                    // the next slab's halo (stored after P_8) is complete
+    // ---- the tile stream
+    for (int k = 0;; ++k) {
+        const bool has_next = lg + (k + 1) * sc.lgroups < cnt;
+        opaque(hp0); opaque(hy0); opaque(hx0);
+        int n_img = c_img, n_ty0 = c_ty0, n_tx0 = c_tx0;
+        if (has_next) decode(s_cur + sc.lgroups, n_img, n_ty0, n_tx0);
+        const unsigned c_pad = pad_of(c_ty0, c_tx0), n_pad = pad_of(n_ty0, n_tx0);
+        zero_acc();              // at the TOP of the tile: the accumulators are not live around the loop's back edge
+        W32_TR(7);
+        for (int slab = 0; slab < nslab; ++slab) {
+            // what is staged during this slab: the tile's next slab, or slab 0 of the next tile (without a next tile:
+            // this tile's slab 0 again -- never read; the operation counts per window do not change)
+            if (slab + 1 < nslab) set_stage(c_img, c_ty0, c_tx0, c_pad, slab + 1);
+            else set_stage(n_img, n_ty0, n_tx0, n_pad, 0);
+            opaque(hrel0); opaque(wrapm); opaque(st_off); opaque(st_last); opaque(x_base); opaque(xm16); opaque(w_off);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool settled = slab == 0;
+            static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, settled, tc); });
+            if (slab + 1 == nslab) wait_vmcnt<0>();           // tile border: the next tile's B[1], B[2] have landed
+            lds_barrier();                                    // the staged halo (stored after P_8) is complete
 #pragma unroll
-        for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
-        W32_TR(5);
+            for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+            W32_TR(5);
+        }
+        epilogue(c_img, c_ty0, c_tx0);
+        W32_TR(6);
+        if (!has_next) break;
+        s_cur += sc.lgroups;
+        c_img = n_img; c_ty0 = n_ty0; c_tx0 = n_tx0;
     }
-    // the tail windows issued DMA and (unused) halo loads: everything must have landed before LDS / registers are reused
+    // the last tile's tail windows issued DMA / halo loads nobody reads: they must land before the workgroup's LDS and
+    // registers are released
     wait_vmcnt<0>();
 #pragma unroll
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
-
-    // ---- epilogue: alpha, bias, residual, 16-byte stores, GroupNorm partial sums of what was stored.
-    // acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channel j*32 + 8*(r>>2) + 4*lh + (r&3).  Register quads
-    // (2m, 2m+1) are half-exchanged so lanes 0-31 own channels j*32+16m .. +7 and lanes 32-63 the next 8.
-    const T* __restrict__ res = (const T*)p.res;
-    const int ox = tx0 + l31;
-    const bool do_stats = p.gn_part != nullptr;
-    float gs[FN][4], gq[FN][4];                      // per (fragment, m, quad-in-chunk): this lane's sums over its FM pixels
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { gs[j][q] = 0.f; gq[j][q] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int cw = wn * WTN + j * 32 + m * 16 + lh * 8;          // channel inside the workgroup's tile
-            const int n = n0 + cw;
-            float bv[8];
-            if (bias_lds) {
-                const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + cw * 4), b1 = *(const f32x4*)(i2i_smem + BI0 + cw * 4 + 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) bv[r] = 0.f;
-            }
-            chunk_t rres[FM];
-            if (res) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int oy = ty0 + wm * FM + i;
-                    const bool ok = ox < p.wo && oy < p.ho && n < p.N;
-                    const int64_t mm = ((int64_t)img * p.ho + (ok ? oy : ty0)) * p.wo + (ok ? ox : tx0);
-                    rres[i] = *(const chunk_t*)(res + mm * p.ldr + (ok ? n : 0));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][8 * m + r], y = acc[i][j][8 * m + 4 + r];
-                    half_swap(x, y);                                       // wave-wide: before any lane drops out
-                    v[r] = x; v[4 + r] = y;
-                }
-                const int oy = ty0 + wm * FM + i;
-                if (ox >= p.wo || oy >= p.ho || n >= p.N) continue;
-                const int64_t mm = ((int64_t)img * p.ho + oy) * p.wo + ox;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r] + bv[r];
-                if (res) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[i][r]);
-                }
-                chunk_t o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
-                if (!W32_ABL(1)) *(chunk_t*)((T*)p.c + mm * p.ldc + n) = o;
-                if (do_stats) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float f = to_f32<T>(o[r]);
-                        gs[j][2 * m + (r >> 2)] += f; gq[j][2 * m + (r >> 2)] += f * f;
-                    }
-                }
-            }
-        }
-    }
-    // ---- GroupNorm partial sums: lane -> 32 pixels (shuffles) -> wave (LDS) -> workgroup -> one slot per group.
-    // Fixed reduction order: deterministic.  gs[j][q]: quad q = 2m + s covers channels j*32 + 16m + 8*lh + 4s .. +3.
-    if (do_stats) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int mk = 1; mk < 32; mk <<= 1) { gs[j][q] += __shfl_xor(gs[j][q], mk); gq[j][q] += __shfl_xor(gq[j][q], mk); }
-        lds_barrier();                                   // every wave is done with its fragments, all DMA landed (vmcnt 0 above)
-        float* st = (float*)i2i_smem;                    // [NW][WTN/4 quads][2]
-        if (l31 == 0) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int quad = (j * 32 + (q >> 1) * 16 + lh * 8 + (q & 1) * 4) >> 2;
-                    st[(wave * (WTN / 4) + quad) * 2 + 0] = gs[j][q];
-                    st[(wave * (WTN / 4) + quad) * 2 + 1] = gq[j][q];
-                }
-        }
-        lds_barrier();
-        const int groups = p.gn_part_groups, cpg = p.N / groups;
-        const int ng_tile = BN / cpg;
-        const int g = n0 / cpg + tid;
-        if (tid < ng_tile && g < groups) {
-            const int c0w = tid * cpg;
-            const int wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
-            float S = 0.f, Q = 0.f;
-            for (int wmm = 0; wmm < WM; ++wmm)
-                for (int q = q0; q < q0 + nq; ++q) {
-                    S += st[((wmm * WN + wnn) * (WTN / 4) + q) * 2 + 0];
-                    Q += st[((wmm * WN + wnn) * (WTN / 4) + q) * 2 + 1];
-                }
-            const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
-            float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
-            out[0] = S;
-            out[1] = Q;
-        }
-    }
 #ifdef I2I_TRACE
-    W32_TR(6);
+    W32_TR(7);
     if (p.ws && lane == 0) {
         unsigned* o = (unsigned*)p.ws + ((size_t)blockIdx.x * NW + wave) * 16;
 #pragma unroll
@@ -487,13 +617,39 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #undef W32_ABL
 }
 
+// workgroups per (XCD, channel tile) of a launch: the resident ones (one per CU).  I2I_W32_LGROUPS overrides: a test hook
+// (small tensors would otherwise never put two tiles on one workgroup), read per launch.
+int w32_lgroups(int ntn, int nsp) {
+    static int ncu = 0;
+    if (!ncu) {
+#ifdef I2I_EMU
+        ncu = 256;
+#else
+        hipDeviceProp_t pr;
+        int dev = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+#endif
+    }
+    int l = (ncu / 8) / ntn;
+    const char* e = getenv("I2I_W32_LGROUPS");
+    if (e && atoi(e) > 0) l = atoi(e);
+    const int per_xcd = (nsp + 7) / 8;
+    if (l > per_xcd) l = per_xcd;
+    return l < 1 ? 1 : l;
+}
+
 template <typename T, int TH, int BN, int WM, int WN>
 int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
-    const unsigned tiles = (unsigned)(((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + TH - 1) / TH) * p.nimg * ((p.N + BN - 1) / BN));
-    const bool gn = p.gn_ss != nullptr;
-    const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
-    if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
-    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
+    w32_sched sc;
+    sc.tiles_x = (p.wo + W32_TW - 1) / W32_TW;
+    sc.tiles_y = (p.ho + TH - 1) / TH;
+    sc.nsp = sc.tiles_x * sc.tiles_y * p.nimg;
+    sc.ntn = (p.N + BN - 1) / BN;
+    sc.lgroups = w32_lgroups(sc.ntn, sc.nsp);
+    const unsigned wgs = 8u * (unsigned)sc.ntn * (unsigned)sc.lgroups;
+    const size_t smem = w32_lds_bytes(TH, BN, WM * WN);
+    if (p.gn_ss) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true>), dim3(wgs), dim3(WM * WN * 64), smem, s, p, sc);
+    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false>), dim3(wgs), dim3(WM * WN * 64), smem, s, p, sc);
     return i2i::check_launch("conv3x3_w32");
 }
 
@@ -524,24 +680,22 @@ int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
 }  // namespace
 
 namespace i2i {
-// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
-// counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
-// together with SiLU.  Not the sub-pixel form.
+// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 without an upsampling gather, 64-aligned channel counts, plane at least
+// one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only together with SiLU.
 bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.subpix || p.out_f32 || p.act_out) return false;
-    if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
+    if (p.ups || p.up_h || p.up_w || p.ho != p.hin || p.wo != p.win) return false;
+    if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK) return false;
     if (p.wo < W32_TW || p.ho < 8 || p.N < 128 || p.N % 8) return false;
-    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
-    if ((p.up_h || p.up_w) && p.ups != 1) return false;
     if (p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     if (p.gn_ss && p.act != 1) return false;
     if (!p.gn_ss && p.act) return false;
     return true;
 }
-// tile == 0 routing: the wide tiles win on every VAE shape that fills the chip (profiles/r3_w32_ab_*.log: +20..24 % over
-// the halo conv with the GroupNorm prologue); channel counts that are not multiples of 128 would waste a third of a tile
-// and grids below ~7/8 of the CUs (UNet planes, batch 1) are better served by the 8x16 tiles of the halo conv.
+// tile == 0 routing: the wide tiles win on every VAE shape that fills the chip (profiles/r3_w32_ab_*.log); channel counts
+// that are not multiples of 128 would waste a third of a tile and grids below ~7/8 of the CUs (UNet planes, batch 1) are
+// better served by the 8x16 tiles of the halo conv.
 bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype) {
     if (!conv3x3_w32_eligible(p, dtype) || p.N % 128) return false;
     int th, bn, wtn;
@@ -554,7 +708,7 @@ int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     const int cpg = p.N / groups;
     int th, bn, wtn;
     w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
-    if (cpg % 4 || wtn % cpg || bn % cpg) return 0;
+    if (wtn % cpg || bn % cpg) return 0;
     return ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + th - 1) / th);
 }
 int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {

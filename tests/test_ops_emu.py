@@ -363,18 +363,24 @@ def test_image_prep_options_match_the_reference_transforms(emu_lib):
 W32_TILES = [41, 42]
 
 
+@pytest.mark.parametrize("lgroups", [None, "1"])
 @pytest.mark.parametrize("cfg", W32_TILES)
-def test_w32_conv_every_tile_config(emu_lib, cfg):
+def test_w32_conv_every_tile_config(emu_lib, cfg, lgroups, monkeypatch):
     """32x32x16-MFMA wide-tile conv: GroupNorm+SiLU staged in the MFMA shadow, residual, ragged tiles in both plane
-    directions, two slabs (the halo hand-over after P_8), ragged channel tile (N = 136 on BN = 128 / 256)."""
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=256, h=10, w=40, gn=True, act=1, groups=8, res=True, tile=cfg)
-    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cin2=64, cout=136, h=17, w=33, tile=cfg, seed=3)
+    directions, two slabs (the halo stored after P_8), ragged channel tile (N = 136 on BN = 128 / 256).  lgroups = 1: one
+    workgroup per (XCD, channel tile), so every workgroup walks SEVERAL tiles -- the next tile's halo, GroupNorm constants
+    and weights are staged across the tile border, the epilogue's stores overlap the next tile, images change mid-stream."""
+    if lgroups:
+        monkeypatch.setenv("I2I_W32_LGROUPS", lgroups)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=3, cin=128, cout=256, h=20, w=72, gn=True, act=1, groups=8, res=True, tile=cfg)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cin2=64, cout=136, h=33, w=65, tile=cfg, seed=3)
 
 
-def test_w32_conv_upsample_three_slabs_and_route(emu_lib):
-    """Nearest-2x gather while staging (non sub-pixel form), three slabs over a concat seam, explicit upsample size; the
-    route query names the kernel the dispatcher picks."""
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=128, h=8, w=16, ups=1, gn=True, act=1, groups=8, tile=42)
+def test_w32_conv_three_slabs_one_slab_and_route(emu_lib, monkeypatch):
+    monkeypatch.setenv("I2I_W32_LGROUPS", "1")
+    """Three slabs over a concat seam, one-slab tiles (every slab is a tile's first and last), alpha; the route query names
+    the kernel the dispatcher picks."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=128, h=16, w=32, gn=True, act=1, groups=8, tile=42)
     oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=9, w=32, res=True, alpha=0.5, tile=41)
     x = torch.zeros(8, 128, 128, 128, dtype=torch.bfloat16)
     w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16)
@@ -390,9 +396,12 @@ def test_w32_conv_upsample_three_slabs_and_route(emu_lib):
     assert emu_lib.igemm_route(p3, K.F32) == "conv3x3_halo_kernel"          # exact-f32 parity mode stays on the halo kernel
 
 
+@pytest.mark.parametrize("lgroups", [None, "1"])
 @pytest.mark.parametrize("cfg", [41, 42])
-def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg):
+def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, lgroups, monkeypatch):
     """The epilogue's GroupNorm partial sums of the STORED output (one slot per tile and group), finished by gn_stats."""
+    if lgroups:
+        monkeypatch.setenv("I2I_W32_LGROUPS", lgroups)
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=64, groups=32, tile=cfg)      # cpg 8
     oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=20, w=40, groups=32, tile=cfg, res=False)   # cpg 4, ragged tiles
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=512, h=8, w=32, groups=32, tile=cfg)       # cpg 16

@@ -208,3 +208,25 @@ def test_lanczos_resize_u8_is_bit_identical_to_pillow(gpu_lib):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print("[resize] 32 x 1280x720 -> 512x512: %.3f ms, %.0f GB/s of input+output bytes" % (dt * 1e3, (x.numel() + y.numel()) / dt / 1e9))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_conv_every_tile_config(gpu_lib, cfg):
+    """Wide-tile 32x32x16-MFMA conv (conv3x3_w32.hip) on the real asynchrony: counted vmcnt weight ring, hidden halo loads,
+    GroupNorm+SiLU in the MFMA shadow, halo stored after the slab's last step barrier.  Repeated with fresh seeds: a race
+    shows up as a sporadic mismatch."""
+    for rep in range(3):
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=40, w=72, gn=True, act=1, groups=8, res=True, tile=cfg, seed=rep)
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=1, cin=64, cin2=128, cout=136, h=33, w=65, gn=True, act=1, groups=8, tile=cfg, seed=rep)
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=3, cin=256, cout=384, h=24, w=64, tile=cfg, seed=rep)
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=9, cin=64, cout=128, h=64, w=96, res=True, tile=cfg, seed=rep)       # > 1 tile per workgroup
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=64, w=64, groups=32, tile=cfg)
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=1, cin=64, cout=128, h=40, w=72, groups=32, tile=cfg, res=False)
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=8, cin=128, cout=128, h=64, w=128, groups=32, tile=0)      # auto route: 8 x 4 x 4 = 128 ... halo
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=8, cin=64, cout=128, h=128, w=128, groups=32, tile=0)      # auto route: 256 wide tiles
