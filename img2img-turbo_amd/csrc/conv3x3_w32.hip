@@ -68,6 +68,17 @@ template <typename V> __device__ __forceinline__ void opaque(V&) {}
 template <typename V> __device__ __forceinline__ void opaque(V& x) { asm volatile("" : "+v"(x)); }
 #endif
 
+// c + a.x*b.x + a.y*b.y in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#ifdef I2I_EMU
+__device__ __forceinline__ float dot2acc(bf16x2_t a, bf16x2_t b, float c) { return fmaf((float)a[1], (float)b[1], fmaf((float)a[0], (float)b[0], c)); }
+__device__ __forceinline__ float dot2acc(f16x2_t a, f16x2_t b, float c) { return fmaf((float)a[1], (float)b[1], fmaf((float)a[0], (float)b[0], c)); }
+#else
+__device__ __forceinline__ float dot2acc(bf16x2_t a, bf16x2_t b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+__device__ __forceinline__ float dot2acc(f16x2_t a, f16x2_t b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+#endif
+
 #ifdef I2I_EMU
 __device__ __forceinline__ int mul24(int a, int b) { return a * b; }
 #else
@@ -81,7 +92,7 @@ constexpr int w32_plane(int th) { return (((th + 2) * (W32_TW + 2) * 32 + 127) /
 // the halo planes and the weight ring allows
 constexpr int w32_stage_px(int bn) { return bn <= 128 ? 32 : 16; }
 constexpr size_t w32_lds_bytes(int th, int bn, int nw) {
-    return (size_t)4 * w32_plane(th) + 1024 + (size_t)W32_RING * bn * 128 + 512 + (size_t)bn * 4 + (size_t)nw * w32_stage_px(bn) * 256;
+    return (size_t)4 * w32_plane(th) + 1024 + (size_t)W32_RING * bn * 128 + 1024 + (size_t)bn * 4 + (size_t)nw * w32_stage_px(bn) * 256;
 }
 
 // Tile stream of a launch (host side fills it): workgroup b serves channel tile (b>>3) % ntn and, inside the contiguous
@@ -90,7 +101,8 @@ constexpr size_t w32_lds_bytes(int th, int bn, int nw) {
 struct w32_sched { int ntn, lgroups, tiles_x, tiles_y, nsp; };
 
 // GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
-template <typename T, int TH, int BN, int WM, int WN, bool GN>
+// RES: residual tensor added in the epilogue (p.res != nullptr).
+template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const w32_sched sc) {
     constexpr int TW = W32_TW, CK = W32_CK, RING = W32_RING, NTAPS = 9;
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -146,12 +158,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     const int64_t img_stride0 = (int64_t)p.hin * p.win * p.lda0 * (int)sizeof(T), img_stride1 = (int64_t)p.hin * p.win * p.lda1 * (int)sizeof(T);
 
     // LDS map: | 4 halo planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring |
-    //          | GroupNorm (scale, shift) of the slab being staged, 512 B | bias of the channel tile | staging, per wave |
+    //          | GroupNorm (scale, shift) of the slab being staged, 2 x 512 B | bias of the channel tile | staging, per wave |
     constexpr int HS0 = 0;
     constexpr int DUM0 = 4 * PLANE;
     constexpr int BS0 = DUM0 + 1024;
     constexpr int SS0 = BS0 + RING * BN * 128;
-    constexpr int BI0 = SS0 + 512;
+    constexpr int BI0 = SS0 + 1024;
     constexpr int STG0 = BI0 + BN * 4;
     char* Bs = i2i_smem + BS0;
     const bool bias_lds = p.bias_mode == 1;
@@ -239,8 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     };
     auto ss_dma = [&]() __attribute__((always_inline)) {            // every wave writes the same 512 bytes: equal VMEM counts
         if constexpr (GN) {
-            if (lane < CK / 2) glds16(sg_ss + lane * 4, i2i_smem + SS0);
-            else note_vmem(1);     // vmcnt counts the instruction for the whole wave (the emulator's queues are per lane)
+            glds16(sg_ss + (lane & 31) * 4, i2i_smem + SS0);      // 64 lanes x 16 B: lanes 32-63 write a second copy (no exec mask, no branch)
         }
     };
     // GroupNorm affine + SiLU of one parked chunk, in place; padding chunks become exact zeros
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto halo_xform = [&](int j) __attribute__((always_inline)) {
         chunk_t c = rh[j];
         if constexpr (GN) {
+            if constexpr (HPT > 12) load_ssr();        // big halos (80 parked registers): the constants are re-read per chunk
 #pragma unroll
             for (int e = 0; e < 8; ++e) c[e] = from_f32<T>(silu_f(__builtin_fmaf(to_f32<T>(c[e]), ssr[2 * e], ssr[2 * e + 1])));
         }
@@ -292,6 +304,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     for (int t = 0; t < RING; ++t)
 #pragma unroll
         for (int q = 0; q < BPW; ++q) b_dma_q(0, t, t, q);
+    if (!bias_lds) {                                    // no bias: the epilogue adds zeros
+        for (int t = tid; t < BN; t += NT) ((float*)(i2i_smem + BI0))[t] = 0.f;
+    }
     if (bias_lds && wave == NW - 1) {
 #pragma unroll
         for (int q = 0; q < (BN + 255) / 256; ++q) {
@@ -368,8 +383,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
-        constexpr int NRD = FN + (xnext ? FM : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
         constexpr bool HP = decltype(has_pre_c)::value && GN;
+        constexpr int NRD = FN + (xnext ? FM : 0) + ((HP && HPT > 12) ? 4 : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
         // one transform = 8 x (cvt, fma, mul, exp, add, rcp, mul) + 4 cvt_pk + 4 cndmask: 16 transcendental + ~52 other VALU
         constexpr int NV = HP ? (52 + NMM - 1) / NMM : 0, NTR = HP ? (16 + NMM - 1) / NMM : 0;
         static_assert(NRD <= NMM, "");
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             for (int j = tap; j < HPT; j += LW) halo_load(j, true);
         }
         if constexpr (tap == 0) ss_dma();
-        if constexpr (tap == 2) load_ssr();               // constants published by P_2; the previous ones died with tap 8
+        if constexpr (tap == 2 && HPT <= 12) load_ssr();  // constants published by P_2; the previous ones died with tap 8
         constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
         kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
               [&]() __attribute__((always_inline)) {
@@ -436,123 +451,127 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         W32_TR(4);
     };
 
-    // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channel j*32 + 8*(r>>2) + 4*lh +
-    // (r&3); register quads (2m, 2m+1) are half-exchanged so lanes 0-31 own channels j*32+16m .. +7 and lanes 32-63 the
-    // next 8 = 16-byte chunk j*4 + 2m + lh of the pixel's 256-byte row.  Staging image (wave private): pixel row of 256
-    // bytes, chunk c at c ^ (pixel & 15) (conflict-free for the column-of-pixels writes and the row reads).
+    // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channels j*32 + 8*(r>>2) + 4*lh + (r&3):
+    // per register quad a lane owns 4 consecutive channels = an 8-byte piece of the pixel's 256-byte row (the wave's 128
+    // channels).  The pieces go straight into a wave-private LDS image of SPX pixel rows (16-byte chunk c of pixel px at
+    // c ^ (px & 15): conflict-free for the column-of-pixels piece writes and for the row reads), the image is read back as
+    // whole rows -- 16 lanes x 16 bytes per pixel -- for full-line global stores, and the GroupNorm partial sums of the
+    // STORED values are taken from the same registers with v_dot2c (2 channels per instruction; the finest group is a
+    // quad).  The residual is loaded in the row layout (full lines), staged through the same image and added in fp32
+    // before the one rounding.
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    typedef T tx2 __attribute__((ext_vector_type(2)));
     const T* __restrict__ res = (const T*)p.res;
     const bool do_stats = p.gn_part != nullptr;
-    char* const stg = i2i_smem + STG0 + wave * (SPX * 256);
     auto epilogue = [&](int img, int ty0, int tx0) __attribute__((always_inline)) {
-        const int ox = tx0 + l31;
-        const int c16 = lane & 15, p4 = lane >> 4;            // read-back role: chunk c16 of pixels p4, p4+4, ...
-        const int nrb = n0 + wn * WTN + c16 * 8;              // first channel of the read-back chunk
-        float gs[8], gq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+        constexpr bool FULL = false;
+        // every lane constant of the epilogue is re-derived from an opaque copy of the lane id: otherwise LICM computes
+        // the staging / store addresses once per kernel and they sit in (spilled) registers across the whole tile stream
+        int elane = lane;
+        opaque(elane);
+        const int l31 = elane & 31, lh = elane >> 5;
+        const int c16 = elane & 15, p4 = elane >> 4;          // row-layout role: chunk c16 of pixels p4, p4+4, ...
+        char* const stg = i2i_smem + STG0 + wave * (SPX * 256);
+        const int nrb = n0 + wn * WTN + c16 * 8;              // first channel of the row-layout chunk
+        const bool nok = FULL || nrb < p.N;
+        // byte offsets of this lane's row-layout chunk inside the staging image (pixel k*4 + p4) and of its pieces
+        const int rl_off = p4 * 256 + ((c16 ^ p4) << 4);      // + k*1024 + ((k*4) & 12) folded below: (k*4+p4)&15 = (k*4 & 12) | p4
+        const unsigned o_lane = (unsigned)(p4 * p.ldc + nrb), r_lane = RES ? (unsigned)(p4 * p.ldr + nrb) : 0u;
+        tx2 ones;
+        ones[0] = (T)1.0f; ones[1] = (T)1.0f;
+        float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;     // (sum, sum of squares) of the chunk's two channel quads
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            __builtin_amdgcn_sched_barrier(0);                // one tile row at a time: nothing of the next row (its residual loads,
-                                                              // its accumulator reads) may be hoisted into this one's register budget
+            __builtin_amdgcn_sched_barrier(0);                // one tile row at a time (register budget)
             const int oy = ty0 + wm * FM + i;
-            chunk_t rres[FN * 2];
-            if (res) {                                         // residual in the accumulator layout, all loads in flight together
-#pragma unroll
-                for (int jm = 0; jm < FN * 2; ++jm) {
-                    const int n = n0 + wn * WTN + jm * 16 + lh * 8;
-                    const bool ok = ox < p.wo && oy < p.ho && n < p.N;
-                    const int64_t mm = ((int64_t)img * p.ho + (ok ? oy : 0)) * p.wo + (ok ? ox : 0);
-                    rres[jm] = *(const chunk_t*)(res + mm * p.ldr + (ok ? n : 0));
-                }
-            }
-            auto make_o = [&](int jm) __attribute__((always_inline)) -> chunk_t {
-                const int j = jm >> 1, m = jm & 1;
-                const int cw = wn * WTN + jm * 16 + lh * 8;   // channel inside the workgroup's tile
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][8 * m + r], y = acc[i][j][8 * m + 4 + r];
-                    half_swap(x, y);
-                    v[r] = x; v[4 + r] = y;
-                }
-                if (bias_lds) {
-                    const f32x4 b0 = *(const f32x4*)(i2i_smem + BI0 + cw * 4), b1 = *(const f32x4*)(i2i_smem + BI0 + cw * 4 + 16);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = p.alpha * v[r] + b0[r]; v[4 + r] = p.alpha * v[4 + r] + b1[r]; }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = p.alpha * v[r];
-                }
-                if (res) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rres[jm][r]);
-                }
-                chunk_t o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
-                return o;
-            };
-            chunk_t o[NRND == 1 ? 1 : FN * 2];
-            if constexpr (NRND > 1) {
-#pragma unroll
-                for (int jm = 0; jm < FN * 2; ++jm) o[jm] = make_o(jm);
-            }
+            const bool rowok = FULL || oy < p.ho;
+            const int64_t rowpix = ((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0;     // uniform
+            T* const obase = (T*)p.c + rowpix * p.ldc;
+            const T* const rbase = RES ? res + rowpix * p.ldr : nullptr;
 #pragma unroll
             for (int rd = 0; rd < NRND; ++rd) {
-                // stage SPX pixels x 256 bytes: the lanes whose pixel column falls into this round write their 8 chunks
-                wave_sync();                                   // (emulator) the previous round's reads are done
-                if constexpr (NRND == 1) {
+                if constexpr (RES) {                           // (a) residual of the round's pixels, row layout -> stage
+                    chunk_t rr[SPX / 4];
 #pragma unroll
-                    for (int jm = 0; jm < FN * 2; ++jm)
-                        *(chunk_t*)(stg + l31 * 256 + (((jm * 2 + lh) ^ (l31 & 15)) << 4)) = make_o(jm);
-                } else {
-                    if ((l31 / SPX) == rd) {
-                        const int px = l31 % SPX;
-#pragma unroll
-                        for (int jm = 0; jm < FN * 2; ++jm)
-                            *(chunk_t*)(stg + px * 256 + (((jm * 2 + lh) ^ (px & 15)) << 4)) = o[jm];
+                    for (int k = 0; k < SPX / 4; ++k) {
+                        const int pxr = rd * SPX + k * 4;      // pixel column (without p4) inside the tile row
+                        const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < p.wo);
+                        rr[k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(pxr * p.ldr) + r_lane : 0u));
                     }
+#pragma unroll
+                    for (int k = 0; k < SPX / 4; ++k) *(chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4))) = rr[k];
+                    wave_sync();
                 }
-                wave_sync();                                   // (emulator) every lane's chunks are staged
+                if (NRND == 1 || (l31 / SPX) == rd) {          // (b) the lanes of this round's pixel columns finish their pieces
+                    const int px = l31 % SPX;
+                    char* const prow = stg + px * 256 + 8 * lh;
+                    const int pswz = (px & 15) << 4;
 #pragma unroll
-                for (int k = 0; k < SPX / 4; ++k) {
-                    const int px = k * 4 + p4;
-                    const chunk_t c = *(const chunk_t*)(stg + px * 256 + ((c16 ^ (px & 15)) << 4));
-                    const int sx = tx0 + rd * SPX + px;
-                    if (sx < p.wo && oy < p.ho && nrb < p.N) {
-                        if (!W32_ABL(1)) *(chunk_t*)((T*)p.c + (((int64_t)img * p.ho + oy) * p.wo + sx) * p.ldc + nrb) = c;
-                        if (do_stats) {
+                    for (int j = 0; j < FN; ++j) {
+                        __builtin_amdgcn_sched_barrier(0);    // four pieces at a time: 16 accumulators + 16 bias values live
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(c[e]); gs[e] += f; gq[e] += f * f; }
+                        for (int q = 0; q < 4; ++q) {
+                            char* const a = prow + (((j * 4 + q) << 4) ^ pswz);
+                            const f32x4 bq = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + lh * 16);
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(p.alpha, acc[i][j][4 * q + r], bq[r]);
+                            if constexpr (RES) {
+                                const tx4 r4 = *(const tx4*)a;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(r4[r]);
+                            }
+                            tx4 o4;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o4[r] = from_f32<T>(v[r]);
+                            *(tx4*)a = o4;
                         }
                     }
                 }
+                wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                // (c) whole rows back: full-line stores + statistics of what is stored
+                T* const orow = obase + o_lane;
+#pragma unroll
+                for (int k = 0; k < SPX / 4; ++k) {
+                    const int pxr = rd * SPX + k * 4;
+                    chunk_t c = *(const chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4)));
+                    const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < p.wo);
+                    if (ok && !W32_ABL(1)) *(chunk_t*)(orow + (unsigned)(pxr * p.ldc)) = c;
+                    if (!FULL && !ok) c = zero_chunk<T>();
+                    tx2 d0, d1, d2, d3;
+                    d0[0] = c[0]; d0[1] = c[1]; d1[0] = c[2]; d1[1] = c[3]; d2[0] = c[4]; d2[1] = c[5]; d3[0] = c[6]; d3[1] = c[7];
+                    gs0 = dot2acc(d0, ones, gs0); gs0 = dot2acc(d1, ones, gs0);
+                    gq0 = dot2acc(d0, d0, gq0);   gq0 = dot2acc(d1, d1, gq0);
+                    gs1 = dot2acc(d2, ones, gs1); gs1 = dot2acc(d3, ones, gs1);
+                    gq1 = dot2acc(d2, d2, gq1);   gq1 = dot2acc(d3, d3, gq1);
+                }
+                wave_sync();                                   // (emulator) the image is free for the next round
             }
         }
-        // ---- GroupNorm partial sums of the stored values: lane -> the 4 lanes sharing a chunk (2 shuffles) -> wave (its
-        // staging block) -> workgroup -> one slot per (tile, group).  Fixed order: deterministic.
+        // ---- GroupNorm partial sums: lane -> the 4 lanes sharing a chunk (2 shuffles) -> wave (its staging block) ->
+        // workgroup -> one slot per (tile, group).  Fixed order: deterministic.
         if (do_stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                gs[e] += __shfl_xor(gs[e], 16); gs[e] += __shfl_xor(gs[e], 32);
-                gq[e] += __shfl_xor(gq[e], 16); gq[e] += __shfl_xor(gq[e], 32);
-            }
-            wave_sync();
-            float* st = (float*)stg;                         // [128 channels][2]
+            gs0 += __shfl_xor(gs0, 16); gs0 += __shfl_xor(gs0, 32);
+            gq0 += __shfl_xor(gq0, 16); gq0 += __shfl_xor(gq0, 32);
+            gs1 += __shfl_xor(gs1, 16); gs1 += __shfl_xor(gs1, 32);
+            gq1 += __shfl_xor(gq1, 16); gq1 += __shfl_xor(gq1, 32);
+            float* st = (float*)stg;                         // [32 quads][2]
             if (p4 == 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { st[(c16 * 8 + e) * 2 + 0] = gs[e]; st[(c16 * 8 + e) * 2 + 1] = gq[e]; }
+                st[(c16 * 2 + 0) * 2 + 0] = gs0; st[(c16 * 2 + 0) * 2 + 1] = gq0;
+                st[(c16 * 2 + 1) * 2 + 0] = gs1; st[(c16 * 2 + 1) * 2 + 1] = gq1;
             }
             lds_barrier();
             const int groups = p.gn_part_groups, cpg = p.N / groups;
             const int ng_tile = BN / cpg;
-            const int g = n0 / cpg + tid;
-            if (tid < ng_tile && g < groups) {
-                const int c0w = tid * cpg, wnn = c0w / WTN, cl = c0w - wnn * WTN;
+            const int etid = wave * 64 + elane;
+            const int g = n0 / cpg + etid;
+            if (etid < ng_tile && g < groups) {
+                const int c0w = etid * cpg, wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
                 float S = 0.f, Q = 0.f;
                 for (int wmm = 0; wmm < WM; ++wmm) {
                     const float* sw = (const float*)(i2i_smem + STG0 + (wmm * WN + wnn) * (SPX * 256));
-                    for (int c = cl; c < cl + cpg; ++c) { S += sw[c * 2]; Q += sw[c * 2 + 1]; }
+                    for (int q = q0; q < q0 + nq; ++q) { S += sw[q * 2]; Q += sw[q * 2 + 1]; }
                 }
                 const int tile_in_img = (ty0 / TH) * sc.tiles_x + tx0 / TW;
                 float* out = p.gn_part + (((int64_t)img * tiles_per_img + tile_in_img) * groups + g) * 2;
@@ -562,7 +581,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             lds_barrier();                                   // the staging blocks are free again
         }
     };
-
     // first fragments of the first step
     W32_TR(0);
 #pragma unroll
@@ -585,6 +603,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             if (slab + 1 < nslab) set_stage(c_img, c_ty0, c_tx0, c_pad, slab + 1);
             else set_stage(n_img, n_ty0, n_tx0, n_pad, 0);
             opaque(hrel0); opaque(wrapm); opaque(st_off); opaque(st_last); opaque(x_base); opaque(xm16); opaque(w_off);
+#pragma unroll
+            for (int q = 0; q < BPW; ++q) opaque(b_voff[q]);       // (their 64-bit extensions would otherwise live in register pairs)
             __builtin_amdgcn_sched_barrier(0);
             const bool settled = slab == 0;
             static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, settled, tc); });
@@ -648,13 +668,17 @@ int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
     sc.lgroups = w32_lgroups(sc.ntn, sc.nsp);
     const unsigned wgs = 8u * (unsigned)sc.ntn * (unsigned)sc.lgroups;
     const size_t smem = w32_lds_bytes(TH, BN, WM * WN);
-    if (p.gn_ss) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true>), dim3(wgs), dim3(WM * WN * 64), smem, s, p, sc);
-    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false>), dim3(wgs), dim3(WM * WN * 64), smem, s, p, sc);
+    const dim3 g(wgs), b(WM * WN * 64);
+    if (p.gn_ss && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, sc);
+    else if (p.gn_ss) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p, sc);
+    else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p, sc);
+    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false>), g, b, smem, s, p, sc);
     return i2i::check_launch("conv3x3_w32");
 }
 
 // tile ids 40..49 (i2i_igemm_params.tile): 40 = auto among the w32 configurations
-//   41: 8 x 32 px x 256 ch, 4 waves (128 px x 128 ch each, one per SIMD)      42: 16 x 32 px x 128 ch, 4 waves (128 x 128)
+//   41: 8 x 32 px x 256 ch, 4 waves (128 px x 128 ch each, one per SIMD)      42: 12 x 32 px x 128 ch, 4 waves (96 x 128: with
+//   16 rows a thread parks 20 halo chunks = 80 registers and the slab loop spills)
 // (8-wave forms of the same workgroup tiles -- 128 x 64 / 64 x 128 wave tiles at two waves per SIMD -- were built and
 // measured in round 3: within +-3 % of these without the GroupNorm prologue, out of registers with it;
 // profiles/r3_w32_ab_nogn.log.  Removed.)
@@ -665,14 +689,14 @@ int w32_cfg(const i2i_igemm_params& p) {
 }
 void w32_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     if (cfg == 41) { *th = 8; *bn = 256; *wtn = 128; }
-    else { *th = 16; *bn = 128; *wtn = 128; }
+    else { *th = 12; *bn = 128; *wtn = 128; }
 }
 
 template <typename T>
 int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
     switch (w32_cfg(p)) {
         case 41: return launch_w32<T, 8, 256, 2, 2>(p, s);
-        case 42: return launch_w32<T, 16, 128, 4, 1>(p, s);
+        case 42: return launch_w32<T, 12, 128, 4, 1>(p, s);
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3_w32: unknown tile config %d", p.tile);
 }
@@ -708,7 +732,7 @@ int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     const int cpg = p.N / groups;
     int th, bn, wtn;
     w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
-    if (wtn % cpg || bn % cpg) return 0;
+    if (cpg % 4 || wtn % cpg || bn % cpg) return 0;        // the epilogue sums channel quads
     return ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + th - 1) / th);
 }
 int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
