@@ -265,14 +265,36 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             }
         }
     };
-    auto halo_xform = [&](int j) __attribute__((always_inline)) {
-        chunk_t c = rh[j];
+    // The transform of one chunk in 16 half pieces (hp = 2*element + phase) so that the step loop can pin ~4 VALU beside
+    // every MFMA: phase 0 = convert, affine, exponent; phase 1 = reciprocal, product, convert back, zero padding.
+    float xf_a = 0.f, xf_t = 0.f;                       // element in flight between its two phases
+    auto halo_xform_half = [&](int j, int hp) __attribute__((always_inline)) {
+        const int e = hp >> 1;
         if constexpr (GN) {
-            if constexpr (HPT > 12) load_ssr();        // big halos (80 parked registers): the constants are re-read per chunk
-#pragma unroll
-            for (int e = 0; e < 8; ++e) c[e] = from_f32<T>(silu_f(__builtin_fmaf(to_f32<T>(c[e]), ssr[2 * e], ssr[2 * e + 1])));
+            if ((hp & 1) == 0) {
+                float sc, sh;
+                if constexpr (HPT > 12) {                  // big halos (>= 60 parked registers): constants re-read per element pair
+                    if ((e & 1) == 0) {
+                        const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + kc * 64 + (e >> 1) * 16);
+                        ssr[0] = v[0]; ssr[1] = v[1]; ssr[2] = v[2]; ssr[3] = v[3];
+                    }
+                    sc = ssr[2 * (e & 1)]; sh = ssr[2 * (e & 1) + 1];
+                } else {
+                    sc = ssr[2 * e]; sh = ssr[2 * e + 1];
+                }
+                xf_a = __builtin_fmaf(to_f32<T>(rh[j][e]), sc, sh);
+                xf_t = exp2_fast(xf_a * -1.44269504088896341f);
+            } else {
+                const float y = xf_a * __builtin_amdgcn_rcpf(1.0f + xf_t);
+                rh[j][e] = ((sg_pad >> j) & 1u) ? (T)0.0f : from_f32<T>(y);
+            }
+        } else {
+            if (hp == 15) rh[j] = ((sg_pad >> j) & 1u) ? zero_chunk<T>() : rh[j];
         }
-        rh[j] = ((sg_pad >> j) & 1u) ? zero_chunk<T>() : c;
+    };
+    auto halo_xform = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int hp = 0; hp < 16; ++hp) halo_xform_half(j, hp);
     };
     auto halo_store = [&](int j) __attribute__((always_inline)) {
         *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * PPJ * 32)) = rh[j];
@@ -329,20 +351,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     lds_barrier();
 
     // ---- per-lane LDS read bases.  Pixel fragment row = u + c with u = wm*FM*34 + l31 (lane) and c = (i+dy)*34 + dx
-    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only; the row part of c and the k16 plane enter as the
-    // immediate c*32 + kk*PLANE.
-    // (u + c) mod 16 >= 8 for c & 15 = m is bit m of `xm`: base + an XOR of 16 (3 VALU per read instead of 16 registers).
-    const int xu = wm * FM * HW2 + l31;
-    int x_base = HS0 + xu * 32 + (lh << 4);
-    unsigned xm16 = 0;                                  // bit (m + 4) = bit 3 of (xu + m)
+    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only: 16 bases x_off[c & 15]; the row part of c and the
+    // k16 plane enter as the immediate c*32 + kk*PLANE (no address arithmetic in the loop).
+    int x_off[16];
+    {
+        const int xu = wm * FM * HW2 + l31;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) xm16 |= (unsigned)(((xu + m) >> 3) & 1) << (m + 4);
+        for (int m = 0; m < 16; ++m) x_off[m] = HS0 + xu * 32 + ((lh ^ (((xu + m) >> 3) & 1)) << 4);
+    }
     int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
 
     chunk_t xf[2][FM], wf[2][FN];
     auto xread = [&](int tap, int i, int kk) __attribute__((always_inline)) -> chunk_t {
         const int c = (i + tap / 3) * HW2 + tap % 3;
-        return *(const chunk_t*)(i2i_smem + (x_base ^ ((xm16 >> (c & 15)) & 16u)) + (kk * PLANE + c * 32));
+        return *(const chunk_t*)(i2i_smem + x_off[c & 15] + (kk * PLANE + c * 32));
     };
     auto wread = [&](int buf, int j, int kk) __attribute__((always_inline)) -> chunk_t {
         return *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + buf * BN * 128 + j * 4096);
@@ -360,45 +382,40 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     };
     static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
 
-    // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
-    // reads of the NEXT k16 step go out beside its first MFMAs (weights first: the i-major MFMA order needs every weight
-    // fragment and x[0] at once); `post` (DMA pieces / halo stores: LDS writers, which the scheduler keeps behind the
-    // reads issued before them) one per MFMA after that.
+    // One k16 step, pinned MFMA by MFMA (sched_barrier(0) after each: the group solver of sched_group_barrier clumped up to
+    // 110 VALU in front of a single MFMA whenever a step carried a transform).  Beside MFMA m: the half pieces of the parked
+    // chunk's GroupNorm+SiLU that fall to it (`pre`), fragment read m of the NEXT k16 step (weights first: the i-major MFMA
+    // order needs every weight fragment and x[0] at once), then item m - NRD of `post` (DMA pieces / halo stores).
     auto kstep = [&](auto tapc, auto kkc, auto&& pre, auto has_pre_c, auto&& post, auto npost_c) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
         constexpr bool xnext = kk < 3 || tap < NTAPS - 1;          // not across the slab hand-over
         constexpr int ntap = kk < 3 ? tap : tap + 1, nkk = (kk + 1) & 3;
-        pre();
-        wf[nxt][0] = wread(ntap % RING, 0, nkk);                  // 9 % 3 == 0: the next slab's tap 0 too
-        if constexpr (xnext) xf[nxt][0] = xread(ntap, 0, nkk);
-#pragma unroll
-        for (int j = 1; j < FN; ++j) wf[nxt][j] = wread(ntap % RING, j, nkk);
-        if constexpr (xnext) {
-#pragma unroll
-            for (int i = 1; i < FM; ++i) xf[nxt][i] = xread(ntap, i, nkk);
-        }
-        post();
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
-        constexpr bool HP = decltype(has_pre_c)::value && GN;
-        constexpr int NRD = FN + (xnext ? FM : 0) + ((HP && HPT > 12) ? 4 : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
-        // one transform = 8 x (cvt, fma, mul, exp, add, rcp, mul) + 4 cvt_pk + 4 cndmask: 16 transcendental + ~52 other VALU
-        constexpr int NV = HP ? (52 + NMM - 1) / NMM : 0, NTR = HP ? (16 + NMM - 1) / NMM : 0;
+        constexpr int NMM = FM * FN, NPO = decltype(npost_c)::value;
+        constexpr bool HP = decltype(has_pre_c)::value;
+        constexpr int NRD = FN + (xnext ? FM : 0);
         static_assert(NRD <= NMM, "");
+        static_for_w<NMM>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (HP) {
 #pragma unroll
-        for (int m = 0; m < NMM; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (m - NRD < NPO) __builtin_amdgcn_sched_group_barrier(0x210, 1, 0);    // VMEM | DS write
-            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-            if (NTR > 0) __builtin_amdgcn_sched_group_barrier(0x400, NTR, 0);
-        }
-        if constexpr (NPO > NMM - NRD) __builtin_amdgcn_sched_group_barrier(0x210, NPO - (NMM - NRD), 0);
+                for (int hp = 0; hp < 16; ++hp)
+                    if ((hp * NMM) / 16 == m) pre(hp);
+            }
+            if constexpr (m < FN) wf[nxt][m] = wread(ntap % RING, m, nkk);            // 9 % 3 == 0: the next slab's tap 0 too
+            else if constexpr (m < NRD) xf[nxt][m - FN] = xread(ntap, m - FN, nkk);
+            // post items spread over the MFMAs after the reads (all of them beside the last one if there are more)
+            constexpr int room = NMM - NRD;
+            if constexpr (NPO > 0 && m >= NRD) {
+                constexpr int p0 = (NPO * (m - NRD)) / room, p1 = (NPO * (m - NRD + 1)) / room;
+                post(icw<p0>{}, icw<p1>{});
+            }
+            constexpr int i = m / FN, j = m % FN;
+            if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
-    auto none = []() __attribute__((always_inline)) {};
+    auto none = [](auto, auto) __attribute__((always_inline)) {};
 
     constexpr int DMA_OPS = BPW;
     // `settled`: first slab of a tile -- everything issued before it was waited for at the tile border (vmcnt 0), and
@@ -406,14 +423,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto step = [&](int slab, bool settled, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
-        auto xf_q = [&](auto qc) __attribute__((always_inline)) {
+        auto xf_q = [&](auto qc, int hp) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
-            if constexpr (tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
+            if constexpr (tap >= 3 && j < HPT) {
+                if (hp == 0) reg_fence(rh[j]);
+                halo_xform_half(j, hp);
+            }
         };
         auto has_q = [&](int q) constexpr { return tap >= 3 && tap - 3 + q * LW < HPT; };
-        kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
-        kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
-        kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
+        kstep(tapc, icw<0>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<0>{}, hp); }, icw<has_q(0)>{}, none, icw<0>{});
+        kstep(tapc, icw<1>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<1>{}, hp); }, icw<has_q(1)>{}, none, icw<0>{});
+        kstep(tapc, icw<2>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<2>{}, hp); }, icw<has_q(2)>{}, none, icw<0>{});
         __builtin_amdgcn_sched_barrier(0);
         W32_TR(1);
         // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
@@ -434,17 +454,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         }
         if constexpr (tap == 0) ss_dma();
         if constexpr (tap == 2 && HPT <= 12) load_ssr();  // constants published by P_2; the previous ones died with tap 8
+        __builtin_amdgcn_sched_barrier(0);
         constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
-        kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
-              [&]() __attribute__((always_inline)) {
-                  if constexpr (tap == NTAPS - 1) {
+        kstep(tapc, icw<3>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<3>{}, hp); }, icw<has_q(3)>{},
+              [&](auto p0c, auto p1c) __attribute__((always_inline)) {       // items [p0, p1) of (halo stores at tap 8, then DMA pieces)
+                  constexpr int p0 = decltype(p0c)::value, p1 = decltype(p1c)::value;
 #pragma unroll
-                      for (int j = 0; j < HPT; ++j) halo_store(j);
-                  }
-#pragma unroll
-                  for (int q = 0; q < BPW; ++q) {
-                      if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
-                      else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+                  for (int it = p0; it < p1; ++it) {
+                      if (it < NST) halo_store(it);
+                      else {
+                          const int q = it - NST;
+                          if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
+                          else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+                      }
                   }
               }, icw<NST + BPW>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -602,7 +624,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             // this tile's slab 0 again -- never read; the operation counts per window do not change)
             if (slab + 1 < nslab) set_stage(c_img, c_ty0, c_tx0, c_pad, slab + 1);
             else set_stage(n_img, n_ty0, n_tx0, n_pad, 0);
-            opaque(hrel0); opaque(wrapm); opaque(st_off); opaque(st_last); opaque(x_base); opaque(xm16); opaque(w_off);
+            opaque(hrel0); opaque(wrapm); opaque(st_off); opaque(st_last); opaque(w_off);
 #pragma unroll
             for (int q = 0; q < BPW; ++q) opaque(b_voff[q]);       // (their 64-bit extensions would otherwise live in register pairs)
             __builtin_amdgcn_sched_barrier(0);
