@@ -95,9 +95,9 @@ constexpr size_t w32_lds_bytes(int th, int bn, int nw) {
     return (size_t)4 * w32_plane(th) + 1024 + (size_t)W32_RING * bn * 128 + 1024 + (size_t)bn * 4 + (size_t)nw * w32_stage_px(bn) * 256;
 }
 
-// Tile stream of a launch (host side fills it): workgroup b serves channel tile (b>>3) % ntn and, inside the contiguous
-// run of spatial tiles of XCD b & 7 (workgroup b runs on XCD b % 8: neighbouring tiles meet in one L2), the tiles
-// lg, lg + lgroups, ... with lg = (b>>3) / ntn.
+// Tile stream of a launch (host side fills it).  Workgroup b runs on XCD b & 7.  ntn | 8: it serves channel tile XCD % ntn
+// and, of the spatial tiles' (8 / ntn)-way split, run XCD / ntn: tiles lg, lg + lgroups, ... with lg = b >> 3.  Otherwise:
+// channel tile (b>>3) % ntn, the 8-way split's run XCD, lg = (b>>3) / ntn.  Neighbouring tiles meet in one L2 either way.
 struct w32_sched { int ntn, lgroups, tiles_x, tiles_y, nsp; };
 
 // GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
@@ -129,22 +129,39 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // shader cycles (s_memtime) it spends per pipeline segment and writes them to p.ws [workgroup][wave][16]:
     // 0 prologue (once per workgroup), 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3,
     // 5 slab-end wait + barrier + first reads, 6 epilogue, 7 tile set-up (next tile decode, accumulator reset).
-    // p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 8 no MFMAs.
+    // p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 4 no weight DMA in the stream, 8 no MFMAs,
+    // 16 halo loads all from pixel 0 (cache hits), 32 no GroupNorm transform VALU, 64 no step barriers.
 #ifdef I2I_TRACE
     unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned tr_t = (unsigned)__builtin_amdgcn_s_memtime();
 #define W32_TR(k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; } while (0)
+#if I2I_TRACE >= 2
+#define W32_TRS(k) W32_TR(k)      // per-step stamps: four s_memtime round trips per step, they dominate what they measure
+#else
+#define W32_TRS(k) do { } while (0)
+#endif
 #define W32_ABL(bit) ((p.splitk & (bit)) != 0)
 #else
 #define W32_TR(k) do { } while (0)
+#define W32_TRS(k) do { } while (0)
 #define W32_ABL(bit) false
 #endif
 
-    // ---- this workgroup's tile stream
+    // ---- this workgroup's tile stream.  Channel tiles by XCD when their number divides 8: every CU of an XCD then streams
+    // the SAME BN rows of the weight matrix (512 -> 512: 2.4 MB instead of 4.7 MB against a 4 MB L2; with both channel
+    // tiles on one XCD the weight DMA alone cost 30 % of the kernel, profiles/r3g_w32_ablation.log).
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-    const int tn = lb % sc.ntn, lg = lb / sc.ntn;
-    int s_cur, cnt;
-    {
+    int tn, lg, s_cur, cnt;
+    if (8 % sc.ntn == 0) {
+        tn = xcd % sc.ntn;
+        lg = lb;
+        const int ng = 8 / sc.ntn, grp = xcd / sc.ntn;
+        const int q = sc.nsp / ng, r = sc.nsp % ng;
+        s_cur = (grp < r ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + lg;
+        cnt = q + (grp < r ? 1 : 0);
+    } else {
+        tn = lb % sc.ntn;
+        lg = lb / sc.ntn;
         const int q = sc.nsp >> 3, r = sc.nsp & 7;
         s_cur = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lg;
         cnt = q + (xcd < r ? 1 : 0);
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     }
     // slab index past the tile's last = the next tile's slabs (same channel tile: same weights)
     auto b_dma_q = [&](int slab, int tap, int buf, int q) __attribute__((always_inline)) {
+        if (W32_ABL(4)) return;
         const int sl = slab < nslab ? slab : slab - nslab;
         const char* src = (const char*)(bw + (tap * cin + sl * CK));
         glds16_sv(src, b_voff[q], Bs + buf * BN * 128 + (wave + q * NW) * 1024);
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto halo_load = [&](int j, bool hidden) __attribute__((always_inline)) {
         const unsigned pix = (unsigned)(sg_pb + hrel(j)) & (((sg_pad >> j) & 1u) - 1u);      // padding lanes: pixel 0, branch-free
         const unsigned voff = pix * sg_ld + (unsigned)kc * 16u;
-        if (hidden) gload16_uncounted(rh[j], sg_base, voff);
+        if (hidden) gload16_uncounted(rh[j], sg_base, W32_ABL(16) ? (unsigned)kc * 16u : voff);      // (never conditional: the asm's destination must not meet a phi)
         else rh[j] = *(const chunk_t*)(sg_base + voff);
     };
     auto ss_dma = [&]() __attribute__((always_inline)) {            // every wave writes the same 512 bytes: equal VMEM counts
@@ -267,8 +285,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     };
     // The transform of one chunk in 16 half pieces (hp = 2*element + phase) so that the step loop can pin ~4 VALU beside
     // every MFMA: phase 0 = convert, affine, exponent; phase 1 = reciprocal, product, convert back, zero padding.
-    float xf_a = 0.f, xf_t = 0.f;                       // element in flight between its two phases
+    float xf_a = 0.f, xf_t = 0.f, xf_y = 0.f;           // element in flight between its two phases / its dword partner
     auto halo_xform_half = [&](int j, int hp) __attribute__((always_inline)) {
+        if (W32_ABL(32)) return;
         const int e = hp >> 1;
         if constexpr (GN) {
             if ((hp & 1) == 0) {
@@ -286,7 +305,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 xf_t = exp2_fast(xf_a * -1.44269504088896341f);
             } else {
                 const float y = xf_a * __builtin_amdgcn_rcpf(1.0f + xf_t);
-                rh[j][e] = ((sg_pad >> j) & 1u) ? (T)0.0f : from_f32<T>(y);
+                if ((e & 1) == 0) xf_y = y;
+                else {                                     // both halves of a dword: convert, pack, zero padding with ONE select
+                    typedef T tx2_t __attribute__((ext_vector_type(2)));
+                    tx2_t pk;
+                    pk[0] = from_f32<T>(xf_y); pk[1] = from_f32<T>(y);
+                    unsigned w = __builtin_bit_cast(unsigned, pk);
+                    w = ((sg_pad >> j) & 1u) ? 0u : w;
+                    pk = __builtin_bit_cast(tx2_t, w);
+                    rh[j][e - 1] = pk[0]; rh[j][e] = pk[1];
+                }
             }
         } else {
             if (hp == 15) rh[j] = ((sg_pad >> j) & 1u) ? zero_chunk<T>() : rh[j];
@@ -370,17 +398,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         return *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + buf * BN * 128 + j * 4096);
     };
 
-    // Halo chunks of the staged slab: loaded in the windows of taps 0..5 (chunks t, t+6, ...: a load issued after P_t is
-    // covered by the counted wait of P_{t+2}), transformed during step t+3 (q-th chunk of the window beside k16 step q),
-    // stored after P_8 -- when every fragment read of the current halo has completed -- in the shadow of the slab's
-    // last 16 MFMAs.  The GroupNorm constants of the staged slab ride in window 0 and are read after P_2.
-    constexpr int LW = 6;
+    // Window of step s (after P_s, beside k16 step 3): the DMA batch of B[s+3] FIRST, then the halo chunks t, t+5, ... of
+    // the staged slab (taps 0..4) and, in window 0, its GroupNorm constants.  vmcnt retires in order: P_s waits for the DMA
+    // batch of window s-2, i.e. it leaves that window's halo loads, the whole window s-1 in flight -- a halo load (HBM
+    // latency under load: the ablation that served them from cache was 14 % faster) has three steps to land: covered by the
+    // wait of P_{t+3}, transformed during step t+4 (q-th chunk of the window beside k16 step q), stored after P_8 -- when
+    // every fragment read of the current halo has completed -- in the shadow of the slab's last 16 MFMAs.
+    constexpr int LW = 5;
     auto nh = [](int t) constexpr {                    // VMEM operations of window t besides the DMA batch
         int c = 0;
         for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c;
         return c + ((GN && t == 0) ? 1 : 0);
     };
-    static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
+    static_assert(HPT <= 3 * LW, "halo chunks do not fit the windows of taps 0..4 / k16 steps 0..2");
 
     // One k16 step, pinned MFMA by MFMA (sched_barrier(0) after each: the group solver of sched_group_barrier clumped up to
     // 110 VALU in front of a single MFMA whenever a step carried a transform).  Beside MFMA m: the half pieces of the parked
@@ -422,55 +452,58 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // the epilogue's stores sit in the queue: steps 0 and 1 need nothing new and must not wait behind those stores.
     auto step = [&](int slab, bool settled, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
-        // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
+        // chunks loaded in window tap-4 landed before P_{tap-1}: transform the q-th beside k16 step q
         auto xf_q = [&](auto qc, int hp) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
-            if constexpr (tap >= 3 && j < HPT) {
+            constexpr int q = decltype(qc)::value, j = tap - 4 + q * LW;
+            if constexpr (tap >= 4 && j < HPT) {
                 if (hp == 0) reg_fence(rh[j]);
                 halo_xform_half(j, hp);
             }
         };
-        auto has_q = [&](int q) constexpr { return tap >= 3 && tap - 3 + q * LW < HPT; };
+        auto has_q = [&](int q) constexpr { return tap >= 4 && tap - 4 + q * LW < HPT; };
         kstep(tapc, icw<0>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<0>{}, hp); }, icw<has_q(0)>{}, none, icw<0>{});
         kstep(tapc, icw<1>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<1>{}, hp); }, icw<has_q(1)>{}, none, icw<0>{});
         kstep(tapc, icw<2>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<2>{}, hp); }, icw<has_q(2)>{}, none, icw<0>{});
         __builtin_amdgcn_sched_barrier(0);
-        W32_TR(1);
-        // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
-        //    its halo loads (+ constants) and its DMA batch.
+        W32_TRS(1);
+        // -- P_s: publishes B[s+1] (the DMA batch of window s-2).  Outstanding VMEM allowed: the halo loads (+ constants) of
+        //    window s-2 and the whole window s-1.
         if constexpr (tap < 2) {
-            if (!settled) wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+            if (!settled) wait_vmcnt<nh(tap - 2) + DMA_OPS + nh(tap - 1)>();
         } else {
-            wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+            wait_vmcnt<nh(tap - 2) + DMA_OPS + nh(tap - 1)>();
         }
-        W32_TR(2);
-        lds_barrier();
-        W32_TR(3);
-        // -- window after P_s: the staged slab's halo chunks (hidden loads) and constants, then -- beside the MFMAs of
-        //    k16 step 3 -- the DMA of B[s+3] into the ring slot step s just released and, at tap 8, the halo stores
-        if constexpr (tap < LW) {
-#pragma unroll
-            for (int j = tap; j < HPT; j += LW) halo_load(j, true);
-        }
-        if constexpr (tap == 0) ss_dma();
-        if constexpr (tap == 2 && HPT <= 12) load_ssr();  // constants published by P_2; the previous ones died with tap 8
-        __builtin_amdgcn_sched_barrier(0);
+        W32_TRS(2);
+        if (!W32_ABL(64)) lds_barrier();
+        W32_TRS(3);
+        // -- after P_s, all beside the MFMAs of k16 step 3 (nothing but the wait and the barrier is serial): the DMA pieces of
+        //    B[s+3] into the ring slot step s just released beside its first MFMAs, then (at tap 8) the halo stores, the staged
+        //    slab's halo chunks of this window (hidden loads) and, in window 0, its constants.
         constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
-        kstep(tapc, icw<3>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<3>{}, hp); }, icw<has_q(3)>{},
-              [&](auto p0c, auto p1c) __attribute__((always_inline)) {       // items [p0, p1) of (halo stores at tap 8, then DMA pieces)
+        constexpr int NLD = (tap < LW) ? (HPT - tap + LW - 1) / LW : 0;              // halo loads of this window
+        constexpr int NXT = (GN && (tap == 0 || (tap == 3 && HPT <= 12))) ? 1 : 0;    // ss_dma (window 0) / load_ssr (after P_3)
+        auto dma_early = [&](int hp) __attribute__((always_inline)) {
+            if (hp < BPW) {
+                if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, hp);
+                else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, hp);
+            }
+        };
+        static_assert(BPW <= 16 && !has_q(3), "");
+        kstep(tapc, icw<3>{}, dma_early, icw<1>{},
+              [&](auto p0c, auto p1c) __attribute__((always_inline)) {       // items [p0, p1) of (halo stores, halo loads, constants)
                   constexpr int p0 = decltype(p0c)::value, p1 = decltype(p1c)::value;
 #pragma unroll
                   for (int it = p0; it < p1; ++it) {
                       if (it < NST) halo_store(it);
+                      else if (it < NST + NLD) halo_load(tap + (it - NST) * LW, true);
                       else {
-                          const int q = it - NST;
-                          if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
-                          else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+                          if constexpr (tap == 0) ss_dma();
+                          if constexpr (tap == 3 && HPT <= 12) load_ssr();    // constants published by P_3; the previous ones died with tap 8
                       }
                   }
-              }, icw<NST + BPW>{});
+              }, icw<NST + NLD + NXT>{});
         __builtin_amdgcn_sched_barrier(0);
-        W32_TR(4);
+        W32_TRS(4);
     };
 
     // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channels j*32 + 8*(r>>2) + 4*lh + (r&3):
@@ -634,8 +667,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             lds_barrier();                                    // the staged halo (stored after P_8) is complete
 #pragma unroll
             for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
-            W32_TR(5);
+            W32_TRS(5);
         }
+        W32_TR(1);                    // (I2I_TRACE=1: segment 1 = the whole slab loop of the tile)
         epilogue(c_img, c_ty0, c_tx0);
         W32_TR(6);
         if (!has_next) break;
@@ -656,6 +690,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     }
 #endif
 #undef W32_TR
+#undef W32_TRS
 #undef W32_ABL
 }
 
@@ -672,11 +707,12 @@ int w32_lgroups(int ntn, int nsp) {
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
 #endif
     }
-    int l = (ncu / 8) / ntn;
+    const bool by_xcd = 8 % ntn == 0;                   // channel tile = XCD % ntn: all workgroups of an XCD share one
+    int l = by_xcd ? ncu / 8 : (ncu / 8) / ntn;
     const char* e = getenv("I2I_W32_LGROUPS");
     if (e && atoi(e) > 0) l = atoi(e);
-    const int per_xcd = (nsp + 7) / 8;
-    if (l > per_xcd) l = per_xcd;
+    const int per_stream = by_xcd ? (nsp * ntn + 7) / 8 : (nsp + 7) / 8;      // spatial tiles of one (XCD[, channel tile]) stream
+    if (l > per_stream) l = per_stream;
     return l < 1 ? 1 : l;
 }
 
@@ -688,7 +724,7 @@ int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
     sc.nsp = sc.tiles_x * sc.tiles_y * p.nimg;
     sc.ntn = (p.N + BN - 1) / BN;
     sc.lgroups = w32_lgroups(sc.ntn, sc.nsp);
-    const unsigned wgs = 8u * (unsigned)sc.ntn * (unsigned)sc.lgroups;
+    const unsigned wgs = 8u * (unsigned)(8 % sc.ntn == 0 ? 1 : sc.ntn) * (unsigned)sc.lgroups;
     const size_t smem = w32_lds_bytes(TH, BN, WM * WN);
     const dim3 g(wgs), b(WM * WN * 64);
     if (p.gn_ss && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, sc);
