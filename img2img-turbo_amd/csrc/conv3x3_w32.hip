@@ -1,9 +1,9 @@
 // 3x3 stride-1 pad-1 implicit-GEMM convolution, "wide" operating point for gfx950: 32x32x16 MFMA, wave tiles of
-// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file), ONE wave per SIMD, one
-// persistent workgroup per CU walking a stream of tiles.  Same replaced reference ops as conv3x3.hip (F.conv2d of
-// diffusers ResnetBlock2D with the preceding F.group_norm + F.silu and torch.cat folded into the operand staging, bias /
-// residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode, planes
-// narrower than 32, upsampling gathers and grids that cannot fill the chip stay on conv3x3_halo_kernel).
+// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file) at ONE wave per SIMD,
+// or 128 x 64 / 64 x 128 at two.  Same replaced reference ops as conv3x3.hip (F.conv2d of diffusers ResnetBlock2D /
+// Upsample2D with the preceding F.group_norm + F.silu, torch.cat and nearest-2x folded into the operand staging,
+// bias / residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode
+// and planes narrower than 32 stay on conv3x3_halo_kernel).
 //
 // Why a second operating point: the 64x64 wave tile on 16x16x32 MFMAs at two waves per SIMD is
 // issue bound -- per 32 MFMAs (512 matrix cycles) a wave issues 16 ds_read_b128, its DMA share, waits and a barrier.
@@ -11,24 +11,20 @@
 // the MFMA instructions per FLOP, and with 8 issue slots per MFMA and nobody else on the SIMD the GroupNorm+SiLU of
 // the NEXT slab's halo runs in the MFMA shadow instead of in a serial hand-over.
 //
-// Workgroup tile = TH x 32 output pixels of one image x BN channels; WM x WN waves, wave = FM tile rows (one 32-pixel
+// Workgroup = TH x 32 output pixels of one image x BN channels; WM x WN waves, wave = FM tile rows (one 32-pixel
 // fragment each) x FN 32-channel fragments.  K loop = (64-channel slab) x (9 taps) x (4 k16 steps):
-//   * pixels: the (TH+2) x 34 halo of a slab lives in FOUR LDS planes, one per k16 step (rows of 32 bytes, chunk XOR
-//     bit 3 of the row): a fragment read (32 consecutive rows at ANY start, lanes 0-31 chunk 0, lanes 32-63 chunk 1)
-//     is conflict-free and the k16 step is an immediate offset (tools/lds_bank_model.py).  The NEXT slab's halo is
-//     loaded by 16-byte loads hidden from the compiler's waitcnt bookkeeping in the windows of taps 0..5, transformed
-//     (GN affine + SiLU) in registers beside the MFMAs of taps 3..8 and stored after the slab's last step barrier.
+//   * pixels: the (TH+2) x 34 halo of a slab is staged once (16-byte loads hidden from the compiler's waitcnt
+//     bookkeeping -> GN affine + SiLU in registers, spread over the taps -> ds_write_b128 at the slab hand-over);
+//     tap (dy,dx) reads 32 consecutive 128-byte LDS rows starting at (row+dy)*34+dx, lanes 0-31 the even chunk of the
+//     k16 step and lanes 32-63 the odd one.  XOR swizzle chunk ^ ((row>>1)&7): conflict-free for every start row
+//     (tools/lds_bank_model.py).
 //   * weights [N][9*Cin]: LDS-DMA into a 3-deep ring of [BN][64] slabs, swizzle carried by the per-lane source
 //     address, issued right after the step barrier that frees the slot and waited for two steps later with a counted
-//     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free, so the counts are exact.
-//   * ONE s_barrier per step (between k16 steps 2 and 3) + one per slab; fragment reads run one k16 step ahead.
-//   * the slab stream is CONTINUOUS ACROSS TILES: during a tile's last slab the staged halo, the GroupNorm constants
-//     and the ring's tail batches are those of the workgroup's next tile, so a tile costs its MFMAs + its epilogue.
-//     With one workgroup per CU nothing else would cover a prologue (measured 20 % of a 2-slab tile, profiles/r3a_*).
-//   * epilogue: accumulators (lane = 4 consecutive channels of one pixel per register quad, quads half-exchanged with
-//     v_permlane32_swap) -> alpha, bias, residual -> 16-bit -> a wave-private LDS staging block -> read back as whole
-//     256-byte pixel rows -> full-line global stores (the accumulator layout would store 32-byte pieces of 32 lines per
-//     instruction: store-issue bound, 24 % of a 2-slab tile) and the GroupNorm partial sums of the stored values.
+//     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free (tail steps re-fetch valid
+//     weights that nobody reads), so the counts are exact.
+//   * ONE s_barrier per step, between k16 steps 2 and 3; fragment reads run one k16 step ahead of their MFMAs.
+//   * MFMA operands swapped (A = weight rows) so an accumulator lane owns 4 consecutive channels of one pixel per
+//     register quad; quads are half-exchanged with v_permlane32_swap so every lane stores 16 bytes.
 #include <stdlib.h>
 
 #include "i2i_dev.h"
@@ -85,38 +81,24 @@ __device__ __forceinline__ int mul24(int a, int b) { return a * b; }
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }       // v_mul_i32_i24: full rate (operands < 2^23)
 #endif
 
-constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3;
+constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
 // bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
 constexpr int w32_plane(int th) { return (((th + 2) * (W32_TW + 2) * 32 + 127) / 128) * 128 + 32; }
-// pixels per epilogue staging round per wave (a pixel = the wave's 128 channels = 256 bytes): what the LDS left beside
-// the halo planes and the weight ring allows
-constexpr int w32_stage_px(int bn) { return bn <= 128 ? 32 : 16; }
-constexpr size_t w32_lds_bytes(int th, int bn, int nw) {
-    return (size_t)4 * w32_plane(th) + 1024 + (size_t)W32_RING * bn * 128 + 1024 + (size_t)bn * 4 + (size_t)nw * w32_stage_px(bn) * 256;
-}
-
-// Tile stream of a launch (host side fills it).  Workgroup b runs on XCD b & 7.  ntn | 8: it serves channel tile XCD % ntn
-// and, of the spatial tiles' (8 / ntn)-way split, run XCD / ntn: tiles lg, lg + lgroups, ... with lg = b >> 3.  Otherwise:
-// channel tile (b>>3) % ntn, the 8-way split's run XCD, lg = (b>>3) / ntn.  Neighbouring tiles meet in one L2 either way.
-struct w32_sched { int ntn, lgroups, tiles_x, tiles_y, nsp; };
 
 // GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
 // RES: residual tensor added in the epilogue (p.res != nullptr).
 template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const w32_sched sc) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const int xcd_tn) {
     constexpr int TW = W32_TW, CK = W32_CK, RING = W32_RING, NTAPS = 9;
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int HW2 = TW + 2, HALO = (TH + 2) * HW2;
     static_assert(TH % WM == 0 && BN % (32 * WN) == 0, "");
     constexpr int FM = TH / WM, WTN = BN / WN, FN = WTN / 32;
-    static_assert(WTN == 128, "the epilogue stages 256-byte pixel rows per wave");
     constexpr int HPT = (HALO * 8 + NT - 1) / NT;      // halo chunks per thread per slab
-    constexpr int PPJ = NT / 8;                        // halo pixels covered per chunk index j
     constexpr int NPIECE = BN / 8;                     // 1-KiB LDS-DMA pieces per weight slab
     static_assert(NPIECE % NW == 0, "every wave issues the same number of DMA pieces");
     constexpr int BPW = NPIECE / NW;
     constexpr int PLANE = w32_plane(TH);
-    constexpr int SPX = w32_stage_px(BN), NRND = 32 / SPX;       // staging rounds per tile row
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit dtypes only");
 
@@ -127,103 +109,89 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     const int kc = tid & 7;
     // Measurement hook (csrc/build.py --tag trace --defs=-DI2I_TRACE=1; never in the product build): every wave sums the
     // shader cycles (s_memtime) it spends per pipeline segment and writes them to p.ws [workgroup][wave][16]:
-    // 0 prologue (once per workgroup), 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3,
-    // 5 slab-end wait + barrier + first reads, 6 epilogue, 7 tile set-up (next tile decode, accumulator reset).
-    // p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 4 no weight DMA in the stream, 8 no MFMAs,
-    // 16 halo loads all from pixel 0 (cache hits), 32 no GroupNorm transform VALU, 64 no step barriers.
+    // 0 prologue, 1 k16 steps 0-2, 2 counted vmcnt wait, 3 step barrier, 4 window + k16 step 3, 5 slab-end barrier + first
+    // reads, 6 epilogue.  p.splitk carries ablation bits (results are WRONG with any set): 1 no stores, 8 no MFMAs.
 #ifdef I2I_TRACE
     unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned tr_t = (unsigned)__builtin_amdgcn_s_memtime();
 #define W32_TR(k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; } while (0)
-#if I2I_TRACE >= 2
-#define W32_TRS(k) W32_TR(k)      // per-step stamps: four s_memtime round trips per step, they dominate what they measure
-#else
-#define W32_TRS(k) do { } while (0)
-#endif
 #define W32_ABL(bit) ((p.splitk & (bit)) != 0)
 #else
 #define W32_TR(k) do { } while (0)
-#define W32_TRS(k) do { } while (0)
 #define W32_ABL(bit) false
 #endif
 
-    // ---- this workgroup's tile stream.  Channel tiles by XCD when their number divides 8: every CU of an XCD then streams
-    // the SAME BN rows of the weight matrix (512 -> 512: 2.4 MB instead of 4.7 MB against a 4 MB L2; with both channel
-    // tiles on one XCD the weight DMA alone cost 30 % of the kernel, profiles/r3g_w32_ablation.log).
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-    int tn, lg, s_cur, cnt;
-    if (8 % sc.ntn == 0) {
-        tn = xcd % sc.ntn;
-        lg = lb;
-        const int ng = 8 / sc.ntn, grp = xcd / sc.ntn;
-        const int q = sc.nsp / ng, r = sc.nsp % ng;
-        s_cur = (grp < r ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + lg;
-        cnt = q + (grp < r ? 1 : 0);
-    } else {
-        tn = lb % sc.ntn;
-        lg = lb / sc.ntn;
-        const int q = sc.nsp >> 3, r = sc.nsp & 7;
-        s_cur = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lg;
-        cnt = q + (xcd < r ? 1 : 0);
+    // ---- XCD-aware tile id: workgroup b runs on XCD b & 7.  When the number of channel tiles divides 8 (xcd_tn: 1, 2, 4, 8
+    // -- the launcher then sizes the grid as 8 x the longest run) the channel tile is XCD % ntn: every CU of an XCD streams
+    // the SAME BN rows of the weight matrix (512 -> 512: 2.4 MB instead of 4.7 MB against a 4 MB L2; with both channel tiles
+    // on one XCD the weight DMA alone cost 30 % of a kernel, profiles/r3g_w32_ablation.log) and the spatial tiles are split
+    // into 8 / ntn contiguous runs.  Otherwise every XCD gets one contiguous run of (tile, channel tile) pairs.
+    const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
+    const int ntn = (p.N + BN - 1) / BN;
+    int tn, bid;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        if (xcd_tn) {
+            const int nsp = tiles_x * tiles_y * p.nimg, ng = 8 / ntn, grp = xcd / ntn;
+            const int q = nsp / ng, r = nsp % ng;
+            if (idx >= q + (grp < r ? 1 : 0)) return;              // (runs differ by one tile: uniform exit of the surplus workgroup)
+            tn = xcd % ntn;
+            bid = (grp < r ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + idx;
+        } else {
+            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+            tn = bid % ntn; bid /= ntn;
+        }
     }
-    if (lg >= cnt) return;                             // fewer tiles than workgroups (uniform)
+    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * TH;
+    const int img = bid / tiles_y;
     const int n0 = tn * BN;
 
+    const T* __restrict__ a0 = (const T*)p.a0;
+    const T* __restrict__ a1 = (const T*)p.a1;
     const T* __restrict__ bw = (const T*)p.b;
     const int cin = p.c0 + p.c1;
-    const int nslab = cin / CK;
-    const int64_t img_stride0 = (int64_t)p.hin * p.win * p.lda0 * (int)sizeof(T), img_stride1 = (int64_t)p.hin * p.win * p.lda1 * (int)sizeof(T);
+    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
 
-    // LDS map: | 4 halo planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring |
-    //          | GroupNorm (scale, shift) of the slab being staged, 2 x 512 B | bias of the channel tile | staging, per wave |
+    // LDS map.  Halo: FOUR planes, one per k16 step (channels 16*kk .. +15 of the slab), rows of 32 bytes = 2 chunks,
+    // chunk h of row r at physical chunk h ^ ((r>>3)&1): a fragment read (32 consecutive rows, lanes 0-31 chunk 0,
+    // lanes 32-63 chunk 1) is conflict-free for every start row, and the k16 step is a pure immediate offset.  PLANE
+    // = 32 (mod 128) so that the eight chunks of one pixel (8 consecutive lanes of a ds_write_b128) hit distinct banks.
+    // | 4 planes | 1 KiB dummy (stores of the out-of-range lanes of the last chunk row) | weight ring | GN consts | bias |
     constexpr int HS0 = 0;
     constexpr int DUM0 = 4 * PLANE;
     constexpr int BS0 = DUM0 + 1024;
-    constexpr int SS0 = BS0 + RING * BN * 128;
-    constexpr int BI0 = SS0 + 1024;
-    constexpr int STG0 = BI0 + BN * 4;
+    constexpr int SS0 = BS0 + RING * BN * 128;          // [cin][2] fp32
+    const int BI0 = SS0 + (GN ? cin * 8 : 0);           // [BN] fp32
     char* Bs = i2i_smem + BS0;
     const bool bias_lds = p.bias_mode == 1;
 
-    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel hp = v>>3 = (hy, hx), chunk kc = tid&7.
-    // hrel[j] = hy*win + hx is tile independent; the pixel index inside the image is pb + hrel[j] with the tile's
-    // pb = (ty0-1)*win + tx0-1 -- unless the pixel is zero padding (bit j of the tile's pad mask: conv pads the
-    // ACTIVATED tensor, so padding lanes load pixel 0 and the transform replaces them by zeros).
-    // One base + a per-lane wrap mask instead of HPT registers: hp advances by PPJ pixels per j; bit j of `wrapm` says
-    // that step j -> j+1 crosses into the next halo row, which adds (win - 34) on top of the PPJ.
-    int hp0 = tid >> 3, hy0 = hp0 / HW2, hx0 = hp0 - hy0 * HW2;
-    static_assert(PPJ < HW2 || PPJ % HW2 < HW2, "");
-    int hrel0 = hy0 * p.win + hx0;
-    unsigned wrapm = 0;
-    {
-        int hx = hx0;
+    // ---- this thread's halo chunks: chunk id v = tid + j*NT -> halo pixel v>>3, chunk kc = tid&7 (constant).
+    // hpix = pixel index inside image `img` (0 for zero padding, flagged in padmask: conv pads the ACTIVATED tensor).
+    unsigned hpix[HPT], padmask = 0;
 #pragma unroll
-        for (int j = 0; j + 1 < HPT; ++j) {
-            hx += PPJ % HW2;
-            if (hx >= HW2) { hx -= HW2; wrapm |= 1u << j; }
+    for (int j = 0; j < HPT; ++j) {
+        const int hp = (tid >> 3) + j * (NT / 8);
+        unsigned pix = 0;
+        bool pad = true;
+        if (hp < HALO) {
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
+            if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up) {
+                pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
+                pad = false;
+            }
         }
+        hpix[j] = pix;
+        padmask |= (pad ? 1u : 0u) << j;
     }
-    const int row_skip = p.win - HW2;
-    auto hrel = [&](int j) __attribute__((always_inline)) -> int {   // hy_j*win + hx_j
-        return hrel0 + j * (PPJ % HW2) + (j * (PPJ / HW2)) * p.win + mul24(__builtin_popcount(wrapm & ((1u << j) - 1u)), row_skip);
-    };
-    auto pad_of = [&](int ty0, int tx0) __attribute__((always_inline)) -> unsigned {
-        unsigned m = 0;
-        int hy = hy0, hx = hx0;
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            const bool in = hp0 + j * PPJ < HALO && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
-            m |= (in ? 0u : 1u) << j;
-            hx += PPJ % HW2; hy += PPJ / HW2;
-            if (hx >= HW2) { hx -= HW2; ++hy; }
-        }
-        return m;
-    };
-    // LDS store address of chunk j: st_off + j*PPJ*32 (row bit 3 does not change with j); the last chunk row may run
-    // past the halo: those lanes store into the dummy block
-    int st_off = HS0 + (kc >> 1) * PLANE + hp0 * 32 + (((kc & 1) ^ ((hp0 >> 3) & 1)) << 4);
-    int st_last = (hp0 + (HPT - 1) * PPJ < HALO) ? st_off + (HPT - 1) * PPJ * 32 : DUM0 + lane * 16;
+    const char* img0 = (const char*)a0 + (int64_t)img * p.hin * p.win * p.lda0 * (int)sizeof(T);
+    const char* img1 = (const char*)a1 + (int64_t)img * p.hin * p.win * p.lda1 * (int)sizeof(T);
+    // LDS store address of chunk j: st_off + j * (NT/8)*32 (row bit 3 does not change with j); the last chunk row
+    // may run past the halo: those lanes store into the dummy block
+    const int st_off = HS0 + (kc >> 1) * PLANE + (tid >> 3) * 32 + (((kc & 1) ^ (((tid >> 3) >> 3) & 1)) << 4);
+    const int st_last = ((tid >> 3) + (HPT - 1) * (NT / 8) < HALO) ? st_off + (HPT - 1) * (NT / 8) * 32 : DUM0 + lane * 16;
 
     // ---- weight DMA: piece pc = wave + q*NW covers LDS rows pc*8 .. +7; lane -> row pc*8 + (lane>>3), physical
     // chunk lane&7 = source chunk (lane&7) ^ swz3(row).  Rows past N are clamped (their columns are never stored).
@@ -235,125 +203,64 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         n = n < p.N ? n : p.N - 1;
         b_voff[q] = (unsigned)(n * p.ldb + (((lane & 7) ^ swz3(row)) * 8)) * (unsigned)sizeof(T);
     }
-    // slab index past the tile's last = the next tile's slabs (same channel tile: same weights)
+    const int nslab = cin / CK;
+    // step index (slab*9 + tap) may run past the last one at the tail: those fetch slab 0 again (valid, never read)
     auto b_dma_q = [&](int slab, int tap, int buf, int q) __attribute__((always_inline)) {
-        if (W32_ABL(4)) return;
-        const int sl = slab < nslab ? slab : slab - nslab;
+        const int sl = slab < nslab ? slab : 0;
         const char* src = (const char*)(bw + (tap * cin + sl * CK));
         glds16_sv(src, b_voff[q], Bs + buf * BN * 128 + (wave + q * NW) * 1024);
     };
 
-    // ---- the slab being STAGED (next slab of this tile, or slab 0 of the next tile): wave-uniform descriptor
-    const char* sg_base = nullptr;                      // source pointer of its first channel, image included
-    unsigned sg_ld = 0;                                 // pixel stride in bytes
-    int sg_pb = 0;                                      // pixel base (ty0-1)*win + tx0-1
-    unsigned sg_pad = 0;                                // zero-padding mask of this thread's chunks
-    const float* sg_ss = nullptr;                       // its 64 (scale, shift) pairs
-    auto set_stage = [&](int img, int ty0, int tx0, unsigned pad, int slab) __attribute__((always_inline)) {
-        const int ci = slab * CK;
-        sg_base = ci < p.c0 ? (const char*)p.a0 + img * img_stride0 + ci * (int)sizeof(T)
-                            : (const char*)p.a1 + img * img_stride1 + (ci - p.c0) * (int)sizeof(T);
-        sg_ld = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
-        sg_pb = (ty0 - 1) * p.win + tx0 - 1;
-        sg_pad = pad;
-        if constexpr (GN) sg_ss = p.gn_ss + ((int64_t)img * cin + ci) * 2;
-    };
-
     chunk_t rh[HPT];
-    // One 16-byte load per call, always and branch-free
-    auto halo_load = [&](int j, bool hidden) __attribute__((always_inline)) {
-        const unsigned pix = (unsigned)(sg_pb + hrel(j)) & (((sg_pad >> j) & 1u) - 1u);      // padding lanes: pixel 0, branch-free
-        const unsigned voff = pix * sg_ld + (unsigned)kc * 16u;
-        if (hidden) gload16_uncounted(rh[j], sg_base, W32_ABL(16) ? (unsigned)kc * 16u : voff);      // (never conditional: the asm's destination must not meet a phi)
-        else rh[j] = *(const chunk_t*)(sg_base + voff);
-    };
-    auto ss_dma = [&]() __attribute__((always_inline)) {            // every wave writes the same 512 bytes: equal VMEM counts
-        if constexpr (GN) {
-            glds16(sg_ss + (lane & 31) * 4, i2i_smem + SS0);      // 64 lanes x 16 B: lanes 32-63 write a second copy (no exec mask, no branch)
-        }
+    // One 16-byte load per call, always and branch-free (padding lanes read pixel 0 and are zeroed by the transform)
+    auto halo_load = [&](int slab, int j, bool hidden) __attribute__((always_inline)) {
+        const int ci = slab * CK;
+        const char* base = ci < p.c0 ? img0 + ci * (int)sizeof(T) : img1 + (ci - p.c0) * (int)sizeof(T);
+        const unsigned ldb = (unsigned)(ci < p.c0 ? p.lda0 : p.lda1) * (unsigned)sizeof(T);
+        const unsigned voff = hpix[j] * ldb + (unsigned)kc * 16u;
+        if (hidden) gload16_uncounted(rh[j], base, voff);
+        else rh[j] = *(const chunk_t*)(base + voff);
     };
     // GroupNorm affine + SiLU of one parked chunk, in place; padding chunks become exact zeros
-    float ssr[16];                                      // (scale, shift) of this thread's 8 channels of the staged slab
-    auto load_ssr = [&]() __attribute__((always_inline)) {
+    float ssr[16];                                      // (scale, shift) of this thread's 8 channels, slab being staged
+    auto load_ssr = [&](int slab) __attribute__((always_inline)) {
         if constexpr (GN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + kc * 64 + q * 16);
+                const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + (slab * CK + kc * 8) * 8 + q * 16);
                 ssr[4 * q + 0] = v[0]; ssr[4 * q + 1] = v[1]; ssr[4 * q + 2] = v[2]; ssr[4 * q + 3] = v[3];
             }
         }
     };
-    // The transform of one chunk in 16 half pieces (hp = 2*element + phase) so that the step loop can pin ~4 VALU beside
-    // every MFMA: phase 0 = convert, affine, exponent; phase 1 = reciprocal, product, convert back, zero padding.
-    float xf_a = 0.f, xf_t = 0.f, xf_y = 0.f;           // element in flight between its two phases / its dword partner
-    auto halo_xform_half = [&](int j, int hp) __attribute__((always_inline)) {
-        if (W32_ABL(32)) return;
-        const int e = hp >> 1;
-        if constexpr (GN) {
-            if ((hp & 1) == 0) {
-                float sc, sh;
-                if constexpr (HPT > 12) {                  // big halos (>= 60 parked registers): constants re-read per element pair
-                    if ((e & 1) == 0) {
-                        const f32x4 v = *(const f32x4*)(i2i_smem + SS0 + kc * 64 + (e >> 1) * 16);
-                        ssr[0] = v[0]; ssr[1] = v[1]; ssr[2] = v[2]; ssr[3] = v[3];
-                    }
-                    sc = ssr[2 * (e & 1)]; sh = ssr[2 * (e & 1) + 1];
-                } else {
-                    sc = ssr[2 * e]; sh = ssr[2 * e + 1];
-                }
-                xf_a = __builtin_fmaf(to_f32<T>(rh[j][e]), sc, sh);
-                xf_t = exp2_fast(xf_a * -1.44269504088896341f);
-            } else {
-                const float y = xf_a * __builtin_amdgcn_rcpf(1.0f + xf_t);
-                if ((e & 1) == 0) xf_y = y;
-                else {                                     // both halves of a dword: convert, pack, zero padding with ONE select
-                    typedef T tx2_t __attribute__((ext_vector_type(2)));
-                    tx2_t pk;
-                    pk[0] = from_f32<T>(xf_y); pk[1] = from_f32<T>(y);
-                    unsigned w = __builtin_bit_cast(unsigned, pk);
-                    w = ((sg_pad >> j) & 1u) ? 0u : w;
-                    pk = __builtin_bit_cast(tx2_t, w);
-                    rh[j][e - 1] = pk[0]; rh[j][e] = pk[1];
-                }
-            }
-        } else {
-            if (hp == 15) rh[j] = ((sg_pad >> j) & 1u) ? zero_chunk<T>() : rh[j];
-        }
-    };
     auto halo_xform = [&](int j) __attribute__((always_inline)) {
+        chunk_t c = rh[j];
+        if constexpr (GN) {
 #pragma unroll
-        for (int hp = 0; hp < 16; ++hp) halo_xform_half(j, hp);
+            for (int e = 0; e < 8; ++e) c[e] = from_f32<T>(silu_f(__builtin_fmaf(to_f32<T>(c[e]), ssr[2 * e], ssr[2 * e + 1])));
+        }
+        rh[j] = ((padmask >> j) & 1u) ? zero_chunk<T>() : c;
     };
     auto halo_store = [&](int j) __attribute__((always_inline)) {
-        *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * PPJ * 32)) = rh[j];
+        *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * (NT / 8) * 32)) = rh[j];
     };
 
     f32x16 acc[FM][FN];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- tile coordinates
-    const int tiles_per_img = sc.tiles_x * sc.tiles_y;
-    auto decode = [&](int s, int& img, int& ty0, int& tx0) __attribute__((always_inline)) {
-        img = s / tiles_per_img;
-        const int t = s - img * tiles_per_img, ty = t / sc.tiles_x;
-        ty0 = ty * TH;
-        tx0 = (t - ty * sc.tiles_x) * TW;
-    };
-    int c_img, c_ty0, c_tx0;
-    decode(s_cur, c_img, c_ty0, c_tx0);
-
-    // ---- prologue (once per workgroup): weights of steps 0..2, bias, and the first tile's slab 0 synchronously
+    // ---- prologue: weights of steps 0..2, GN constants of every input channel, bias, halo of slab 0
 #pragma unroll
     for (int t = 0; t < RING; ++t)
 #pragma unroll
         for (int q = 0; q < BPW; ++q) b_dma_q(0, t, t, q);
+    if constexpr (GN) {
+        for (int pc = wave; pc * 128 < cin; pc += NW)      // 1 KiB = (scale, shift) of 128 channels per piece
+            if (pc * 128 + lane * 2 < cin) glds16(p.gn_ss + ((int64_t)img * cin + pc * 128 + lane * 2) * 2, i2i_smem + SS0 + pc * 1024);
+    }
     if (!bias_lds) {                                    // no bias: the epilogue adds zeros
         for (int t = tid; t < BN; t += NT) ((float*)(i2i_smem + BI0))[t] = 0.f;
     }
@@ -367,27 +274,25 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             }
         }
     }
-    set_stage(c_img, c_ty0, c_tx0, pad_of(c_ty0, c_tx0), 0);
-    ss_dma();
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) halo_load(j, false);
+    for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
     wait_vmcnt<0>();
     lds_barrier();
-    load_ssr();
+    load_ssr(0);
 #pragma unroll
     for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
     lds_barrier();
 
     // ---- per-lane LDS read bases.  Pixel fragment row = u + c with u = wm*FM*34 + l31 (lane) and c = (i+dy)*34 + dx
-    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only: 16 bases x_off[c & 15]; the row part of c and the
-    // k16 plane enter as the immediate c*32 + kk*PLANE (no address arithmetic in the loop).
+    // (compile time); bit 3 of row u + c depends on (u + c) mod 16 only: 16 bases x_off[c & 15]; the row part of c and
+    // the k16 plane enter as the immediate c*32 + kk*PLANE.
     int x_off[16];
     {
-        const int xu = wm * FM * HW2 + l31;
+        const int u = wm * FM * HW2 + l31;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) x_off[m] = HS0 + xu * 32 + ((lh ^ (((xu + m) >> 3) & 1)) << 4);
+        for (int m = 0; m < 16; ++m) x_off[m] = HS0 + u * 32 + ((lh ^ (((u + m) >> 3) & 1)) << 4);
     }
-    int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
+    const int w_off = BS0 + (wn * WTN + l31) * 128 + ((lh ^ swz3(l31)) << 4);     // fragment j: + j*4096 (swizzle unchanged)
 
     chunk_t xf[2][FM], wf[2][FN];
     auto xread = [&](int tap, int i, int kk) __attribute__((always_inline)) -> chunk_t {
@@ -398,114 +303,123 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         return *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + buf * BN * 128 + j * 4096);
     };
 
-    // Window of step s (after P_s, beside k16 step 3): the DMA batch of B[s+3] FIRST, then the halo chunks t, t+5, ... of
-    // the staged slab (taps 0..4) and, in window 0, its GroupNorm constants.  vmcnt retires in order: P_s waits for the DMA
-    // batch of window s-2, i.e. it leaves that window's halo loads, the whole window s-1 in flight -- a halo load (HBM
-    // latency under load: the ablation that served them from cache was 14 % faster) has three steps to land: covered by the
-    // wait of P_{t+3}, transformed during step t+4 (q-th chunk of the window beside k16 step q), stored after P_8 -- when
-    // every fragment read of the current halo has completed -- in the shadow of the slab's last 16 MFMAs.
-    constexpr int LW = 5;
-    auto nh = [](int t) constexpr {                    // VMEM operations of window t besides the DMA batch
-        int c = 0;
-        for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c;
-        return c + ((GN && t == 0) ? 1 : 0);
-    };
-    static_assert(HPT <= 3 * LW, "halo chunks do not fit the windows of taps 0..4 / k16 steps 0..2");
+    // Halo chunks of the NEXT slab: loaded in the windows of taps 0..5 (chunks t, t+6, ...: a load issued after P_t is
+    // covered by the counted wait of P_{t+2}), transformed during step t+3 (q-th chunk of the window beside k16 step q),
+    // stored after P_8 -- when every fragment read of the current halo has completed -- in the shadow of the slab's
+    // last 16 MFMAs.  ONE extra barrier per slab, no serial hand-over.
+    constexpr int LW = 6;
+    auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c; return c; };
+    static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
 
-    // One k16 step, pinned MFMA by MFMA (sched_barrier(0) after each: the group solver of sched_group_barrier clumped up to
-    // 110 VALU in front of a single MFMA whenever a step carried a transform).  Beside MFMA m: the half pieces of the parked
-    // chunk's GroupNorm+SiLU that fall to it (`pre`), fragment read m of the NEXT k16 step (weights first: the i-major MFMA
-    // order needs every weight fragment and x[0] at once), then item m - NRD of `post` (DMA pieces / halo stores).
+    // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
+    // reads of the NEXT k16 step go out beside its first MFMAs (weights first: the i-major MFMA order needs every weight
+    // fragment and x[0] at once); `post` (DMA pieces / halo stores: LDS writers, which the scheduler keeps behind the
+    // reads issued before them) one per MFMA after that.
     auto kstep = [&](auto tapc, auto kkc, auto&& pre, auto has_pre_c, auto&& post, auto npost_c) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
         constexpr bool xnext = kk < 3 || tap < NTAPS - 1;          // not across the slab hand-over
         constexpr int ntap = kk < 3 ? tap : tap + 1, nkk = (kk + 1) & 3;
-        constexpr int NMM = FM * FN, NPO = decltype(npost_c)::value;
-        constexpr bool HP = decltype(has_pre_c)::value;
-        constexpr int NRD = FN + (xnext ? FM : 0);
-        static_assert(NRD <= NMM, "");
-        static_for_w<NMM>([&](auto mc) __attribute__((always_inline)) {
-            constexpr int m = decltype(mc)::value;
-            if constexpr (HP) {
+        pre();
+        wf[nxt][0] = wread(ntap % RING, 0, nkk);                  // 9 % 3 == 0: the next slab's tap 0 too
+        if constexpr (xnext) xf[nxt][0] = xread(ntap, 0, nkk);
 #pragma unroll
-                for (int hp = 0; hp < 16; ++hp)
-                    if ((hp * NMM) / 16 == m) pre(hp);
-            }
-            if constexpr (m < FN) wf[nxt][m] = wread(ntap % RING, m, nkk);            // 9 % 3 == 0: the next slab's tap 0 too
-            else if constexpr (m < NRD) xf[nxt][m - FN] = xread(ntap, m - FN, nkk);
-            // post items spread over the MFMAs after the reads (all of them beside the last one if there are more)
-            constexpr int room = NMM - NRD;
-            if constexpr (NPO > 0 && m >= NRD) {
-                constexpr int p0 = (NPO * (m - NRD)) / room, p1 = (NPO * (m - NRD + 1)) / room;
-                post(icw<p0>{}, icw<p1>{});
-            }
-            constexpr int i = m / FN, j = m % FN;
-            if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        for (int j = 1; j < FN; ++j) wf[nxt][j] = wread(ntap % RING, j, nkk);
+        if constexpr (xnext) {
+#pragma unroll
+            for (int i = 1; i < FM; ++i) xf[nxt][i] = xread(ntap, i, nkk);
+        }
+        post();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+        constexpr int NRD = FN + (xnext ? FM : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
+        constexpr bool HP = decltype(has_pre_c)::value && GN;
+        // one transform = 8 x (cvt, fma, mul, exp, add, rcp, mul) + 4 cvt_pk + 4 cndmask: 16 transcendental + ~52 other VALU
+        constexpr int NV = HP ? (52 + NMM - 1) / NMM : 0, NTR = HP ? (16 + NMM - 1) / NMM : 0;
+        static_assert(NRD <= NMM, "");
+#pragma unroll
+        for (int m = 0; m < NMM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (m - NRD < NPO) __builtin_amdgcn_sched_group_barrier(0x210, 1, 0);    // VMEM | DS write
+            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            if (NTR > 0) __builtin_amdgcn_sched_group_barrier(0x400, NTR, 0);
+        }
+        if constexpr (NPO > NMM - NRD) __builtin_amdgcn_sched_group_barrier(0x210, NPO - (NMM - NRD), 0);
     };
-    auto none = [](auto, auto) __attribute__((always_inline)) {};
+    auto none = []() __attribute__((always_inline)) {};
 
     constexpr int DMA_OPS = BPW;
-    // `settled`: first slab of a tile -- everything issued before it was waited for at the tile border (vmcnt 0), and
-    // the epilogue's stores sit in the queue: steps 0 and 1 need nothing new and must not wait behind those stores.
-    auto step = [&](int slab, bool settled, auto tapc) __attribute__((always_inline)) {
+    auto step = [&](int slab, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
-        // chunks loaded in window tap-4 landed before P_{tap-1}: transform the q-th beside k16 step q
-        auto xf_q = [&](auto qc, int hp) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value, j = tap - 4 + q * LW;
-            if constexpr (tap >= 4 && j < HPT) {
-                if (hp == 0) reg_fence(rh[j]);
-                halo_xform_half(j, hp);
-            }
+        // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
+        auto xf_q = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
+            if constexpr (tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
         };
-        auto has_q = [&](int q) constexpr { return tap >= 4 && tap - 4 + q * LW < HPT; };
-        kstep(tapc, icw<0>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<0>{}, hp); }, icw<has_q(0)>{}, none, icw<0>{});
-        kstep(tapc, icw<1>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<1>{}, hp); }, icw<has_q(1)>{}, none, icw<0>{});
-        kstep(tapc, icw<2>{}, [&](int hp) __attribute__((always_inline)) { xf_q(icw<2>{}, hp); }, icw<has_q(2)>{}, none, icw<0>{});
+        auto has_q = [&](int q) constexpr { return tap >= 3 && tap - 3 + q * LW < HPT; };
+        kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
+        kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
+        kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
         __builtin_amdgcn_sched_barrier(0);
-        W32_TRS(1);
-        // -- P_s: publishes B[s+1] (the DMA batch of window s-2).  Outstanding VMEM allowed: the halo loads (+ constants) of
-        //    window s-2 and the whole window s-1.
-        if constexpr (tap < 2) {
-            if (!settled) wait_vmcnt<nh(tap - 2) + DMA_OPS + nh(tap - 1)>();
-        } else {
-            wait_vmcnt<nh(tap - 2) + DMA_OPS + nh(tap - 1)>();
-        }
-        W32_TRS(2);
-        if (!W32_ABL(64)) lds_barrier();
-        W32_TRS(3);
-        // -- after P_s, all beside the MFMAs of k16 step 3 (nothing but the wait and the barrier is serial): the DMA pieces of
-        //    B[s+3] into the ring slot step s just released beside its first MFMAs, then (at tap 8) the halo stores, the staged
-        //    slab's halo chunks of this window (hidden loads) and, in window 0, its constants.
-        constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
-        constexpr int NLD = (tap < LW) ? (HPT - tap + LW - 1) / LW : 0;              // halo loads of this window
-        constexpr int NXT = (GN && (tap == 0 || (tap == 3 && HPT <= 12))) ? 1 : 0;    // ss_dma (window 0) / load_ssr (after P_3)
-        auto dma_early = [&](int hp) __attribute__((always_inline)) {
-            if (hp < BPW) {
-                if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, hp);
-                else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, hp);
-            }
-        };
-        static_assert(BPW <= 16 && !has_q(3), "");
-        kstep(tapc, icw<3>{}, dma_early, icw<1>{},
-              [&](auto p0c, auto p1c) __attribute__((always_inline)) {       // items [p0, p1) of (halo stores, halo loads, constants)
-                  constexpr int p0 = decltype(p0c)::value, p1 = decltype(p1c)::value;
+        W32_TR(1);
+        // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
+        //    its halo loads and its DMA batch.
+        wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        W32_TR(2);
+        lds_barrier();
+        W32_TR(3);
+        // -- window after P_s: next slab's halo chunks (hidden loads; from this slab again when there is no next one, the
+        //    count per window never changes), then -- beside the MFMAs of k16 step 3 -- the DMA of B[s+3] into the ring
+        //    slot step s just released and, at tap 8, the stores of the next slab's halo
+        {
+            const int hs = slab + 1 < nslab ? slab + 1 : slab;
+            if constexpr (tap < LW) {
 #pragma unroll
-                  for (int it = p0; it < p1; ++it) {
-                      if (it < NST) halo_store(it);
-                      else if (it < NST + NLD) halo_load(tap + (it - NST) * LW, true);
-                      else {
-                          if constexpr (tap == 0) ss_dma();
-                          if constexpr (tap == 3 && HPT <= 12) load_ssr();    // constants published by P_3; the previous ones died with tap 8
-                      }
+                for (int j = tap; j < HPT; j += LW) halo_load(hs, j, true);
+            }
+        }
+        constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
+        kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
+              [&]() __attribute__((always_inline)) {
+                  if constexpr (tap == NTAPS - 1) {
+#pragma unroll
+                      for (int j = 0; j < HPT; ++j) halo_store(j);
                   }
-              }, icw<NST + NLD + NXT>{});
+#pragma unroll
+                  for (int q = 0; q < BPW; ++q) {
+                      if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
+                      else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+                  }
+              }, icw<NST + BPW>{});
         __builtin_amdgcn_sched_barrier(0);
-        W32_TRS(4);
+        W32_TR(4);
     };
 
+    // first fragments of the first step
+    W32_TR(0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[0][j] = wread(0, j, 0);
+
+    for (int slab = 0; slab < nslab; ++slab) {
+        load_ssr(slab + 1 < nslab ? slab + 1 : slab);     // constants of the slab whose halo is transformed during this one (from tap 3 on)
+        __builtin_amdgcn_sched_barrier(0);                // (its ds_reads must not take the fragment reads' slots in the pinned schedule)
+        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, tc); });
+        lds_barrier();                                    // the next slab's halo (stored after P_8) is complete
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+        W32_TR(5);
+    }
+    // the tail windows issued DMA and (unused) halo loads: everything must have landed before LDS / registers are reused
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+
+    lds_barrier();                                       // every wave is done with the halo planes / the ring: the staging blocks reuse them
     // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channels j*32 + 8*(r>>2) + 4*lh + (r&3):
     // per register quad a lane owns 4 consecutive channels = an 8-byte piece of the pixel's 256-byte row (the wave's 128
     // channels).  The pieces go straight into a wave-private LDS image of SPX pixel rows (16-byte chunk c of pixel px at
@@ -514,6 +428,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // STORED values are taken from the same registers with v_dot2c (2 channels per instruction; the finest group is a
     // quad).  The residual is loaded in the row layout (full lines), staged through the same image and added in fp32
     // before the one rounding.
+    constexpr int SPX = 32, NRND = 1;                    // a whole 32-pixel tile row per staging round
+    static_assert(WTN == 128 && 4 * w32_plane(TH) >= NW * SPX * 256, "");
     typedef T tx4 __attribute__((ext_vector_type(4)));
     typedef T tx2 __attribute__((ext_vector_type(2)));
     const T* __restrict__ res = (const T*)p.res;
@@ -526,7 +442,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         opaque(elane);
         const int l31 = elane & 31, lh = elane >> 5;
         const int c16 = elane & 15, p4 = elane >> 4;          // row-layout role: chunk c16 of pixels p4, p4+4, ...
-        char* const stg = i2i_smem + STG0 + wave * (SPX * 256);
+        char* const stg = i2i_smem + wave * (SPX * 256);          // the halo planes are dead: 8 KiB per wave from the LDS base
         const int nrb = n0 + wn * WTN + c16 * 8;              // first channel of the row-layout chunk
         const bool nok = FULL || nrb < p.N;
         // byte offsets of this lane's row-layout chunk inside the staging image (pixel k*4 + p4) and of its pieces
@@ -625,64 +541,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 const int c0w = etid * cpg, wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
                 float S = 0.f, Q = 0.f;
                 for (int wmm = 0; wmm < WM; ++wmm) {
-                    const float* sw = (const float*)(i2i_smem + STG0 + (wmm * WN + wnn) * (SPX * 256));
+                    const float* sw = (const float*)(i2i_smem + (wmm * WN + wnn) * (SPX * 256));
                     for (int q = q0; q < q0 + nq; ++q) { S += sw[q * 2]; Q += sw[q * 2 + 1]; }
                 }
-                const int tile_in_img = (ty0 / TH) * sc.tiles_x + tx0 / TW;
-                float* out = p.gn_part + (((int64_t)img * tiles_per_img + tile_in_img) * groups + g) * 2;
+                const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
+                float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
                 out[0] = S;
                 out[1] = Q;
             }
             lds_barrier();                                   // the staging blocks are free again
         }
     };
-    // first fragments of the first step
-    W32_TR(0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) wf[0][j] = wread(0, j, 0);
-
-    // ---- the tile stream
-    for (int k = 0;; ++k) {
-        const bool has_next = lg + (k + 1) * sc.lgroups < cnt;
-        opaque(hp0); opaque(hy0); opaque(hx0);
-        int n_img = c_img, n_ty0 = c_ty0, n_tx0 = c_tx0;
-        if (has_next) decode(s_cur + sc.lgroups, n_img, n_ty0, n_tx0);
-        const unsigned c_pad = pad_of(c_ty0, c_tx0), n_pad = pad_of(n_ty0, n_tx0);
-        zero_acc();              // at the TOP of the tile: the accumulators are not live around the loop's back edge
-        W32_TR(7);
-        for (int slab = 0; slab < nslab; ++slab) {
-            // what is staged during this slab: the tile's next slab, or slab 0 of the next tile (without a next tile:
-            // this tile's slab 0 again -- never read; the operation counts per window do not change)
-            if (slab + 1 < nslab) set_stage(c_img, c_ty0, c_tx0, c_pad, slab + 1);
-            else set_stage(n_img, n_ty0, n_tx0, n_pad, 0);
-            opaque(hrel0); opaque(wrapm); opaque(st_off); opaque(st_last); opaque(w_off);
-#pragma unroll
-            for (int q = 0; q < BPW; ++q) opaque(b_voff[q]);       // (their 64-bit extensions would otherwise live in register pairs)
-            __builtin_amdgcn_sched_barrier(0);
-            const bool settled = slab == 0;
-            static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, settled, tc); });
-            if (slab + 1 == nslab) wait_vmcnt<0>();           // tile border: the next tile's B[1], B[2] have landed
-            lds_barrier();                                    // the staged halo (stored after P_8) is complete
-#pragma unroll
-            for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
-            W32_TRS(5);
-        }
-        W32_TR(1);                    // (I2I_TRACE=1: segment 1 = the whole slab loop of the tile)
-        epilogue(c_img, c_ty0, c_tx0);
-        W32_TR(6);
-        if (!has_next) break;
-        s_cur += sc.lgroups;
-        c_img = n_img; c_ty0 = n_ty0; c_tx0 = n_tx0;
-    }
-    // the last tile's tail windows issued DMA / halo loads nobody reads: they must land before the workgroup's LDS and
-    // registers are released
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
+    epilogue(img, ty0, tx0);
 #ifdef I2I_TRACE
-    W32_TR(7);
+    W32_TR(6);
     if (p.ws && lane == 0) {
         unsigned* o = (unsigned*)p.ws + ((size_t)blockIdx.x * NW + wave) * 16;
 #pragma unroll
@@ -690,53 +562,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     }
 #endif
 #undef W32_TR
-#undef W32_TRS
 #undef W32_ABL
-}
-
-// workgroups per (XCD, channel tile) of a launch: the resident ones (one per CU).  I2I_W32_LGROUPS overrides: a test hook
-// (small tensors would otherwise never put two tiles on one workgroup), read per launch.
-int w32_lgroups(int ntn, int nsp) {
-    static int ncu = 0;
-    if (!ncu) {
-#ifdef I2I_EMU
-        ncu = 256;
-#else
-        hipDeviceProp_t pr;
-        int dev = 0;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-#endif
-    }
-    const bool by_xcd = 8 % ntn == 0;                   // channel tile = XCD % ntn: all workgroups of an XCD share one
-    int l = by_xcd ? ncu / 8 : (ncu / 8) / ntn;
-    const char* e = getenv("I2I_W32_LGROUPS");
-    if (e && atoi(e) > 0) l = atoi(e);
-    const int per_stream = by_xcd ? (nsp * ntn + 7) / 8 : (nsp + 7) / 8;      // spatial tiles of one (XCD[, channel tile]) stream
-    if (l > per_stream) l = per_stream;
-    return l < 1 ? 1 : l;
 }
 
 template <typename T, int TH, int BN, int WM, int WN>
 int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
-    w32_sched sc;
-    sc.tiles_x = (p.wo + W32_TW - 1) / W32_TW;
-    sc.tiles_y = (p.ho + TH - 1) / TH;
-    sc.nsp = sc.tiles_x * sc.tiles_y * p.nimg;
-    sc.ntn = (p.N + BN - 1) / BN;
-    sc.lgroups = w32_lgroups(sc.ntn, sc.nsp);
-    const unsigned wgs = 8u * (unsigned)(8 % sc.ntn == 0 ? 1 : sc.ntn) * (unsigned)sc.lgroups;
-    const size_t smem = w32_lds_bytes(TH, BN, WM * WN);
-    const dim3 g(wgs), b(WM * WN * 64);
-    if (p.gn_ss && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, sc);
-    else if (p.gn_ss) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p, sc);
-    else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p, sc);
-    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false>), g, b, smem, s, p, sc);
+    const int nsp = ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + TH - 1) / TH) * p.nimg, ntn = (p.N + BN - 1) / BN;
+    const bool xcd_off = getenv("I2I_W32_XCDTN") && atoi(getenv("I2I_W32_XCDTN")) == 0;      // A/B / test hook, read per launch
+    const int xcd_tn = (8 % ntn == 0 && !xcd_off) ? 1 : 0;
+    const unsigned tiles = xcd_tn ? 8u * (unsigned)((nsp + 8 / ntn - 1) / (8 / ntn)) : (unsigned)(nsp * ntn);
+    const bool gn = p.gn_ss != nullptr;
+    const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
+    const dim3 g(tiles), b(WM * WN * 64);
+    if (gn && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, xcd_tn);
+    else if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p, xcd_tn);
+    else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p, xcd_tn);
+    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false>), g, b, smem, s, p, xcd_tn);
     return i2i::check_launch("conv3x3_w32");
 }
 
 // tile ids 40..49 (i2i_igemm_params.tile): 40 = auto among the w32 configurations
-//   41: 8 x 32 px x 256 ch, 4 waves (128 px x 128 ch each, one per SIMD)      42: 12 x 32 px x 128 ch, 4 waves (96 x 128: with
-//   16 rows a thread parks 20 halo chunks = 80 registers and the slab loop spills)
+//   41: 8 x 32 px x 256 ch, 4 waves (128 px x 128 ch each, one per SIMD)      42: 16 x 32 px x 128 ch, 4 waves (128 x 128)
 // (8-wave forms of the same workgroup tiles -- 128 x 64 / 64 x 128 wave tiles at two waves per SIMD -- were built and
 // measured in round 3: within +-3 % of these without the GroupNorm prologue, out of registers with it;
 // profiles/r3_w32_ab_nogn.log.  Removed.)
@@ -747,14 +593,14 @@ int w32_cfg(const i2i_igemm_params& p) {
 }
 void w32_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     if (cfg == 41) { *th = 8; *bn = 256; *wtn = 128; }
-    else { *th = 12; *bn = 128; *wtn = 128; }
+    else { *th = 16; *bn = 128; *wtn = 128; }
 }
 
 template <typename T>
 int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
     switch (w32_cfg(p)) {
         case 41: return launch_w32<T, 8, 256, 2, 2>(p, s);
-        case 42: return launch_w32<T, 12, 128, 4, 1>(p, s);
+        case 42: return launch_w32<T, 16, 128, 4, 1>(p, s);
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3_w32: unknown tile config %d", p.tile);
 }
@@ -762,22 +608,24 @@ int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
 }  // namespace
 
 namespace i2i {
-// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 without an upsampling gather, 64-aligned channel counts, plane at least
-// one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only together with SiLU.
+// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
+// counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
+// together with SiLU.  Not the sub-pixel form.
 bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.subpix || p.out_f32 || p.act_out) return false;
-    if (p.ups || p.up_h || p.up_w || p.ho != p.hin || p.wo != p.win) return false;
-    if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK) return false;
+    if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
     if (p.wo < W32_TW || p.ho < 8 || p.N < 128 || p.N % 8) return false;
+    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
+    if ((p.up_h || p.up_w) && p.ups != 1) return false;
     if (p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     if (p.gn_ss && p.act != 1) return false;
     if (!p.gn_ss && p.act) return false;
     return true;
 }
-// tile == 0 routing: the wide tiles win on every VAE shape that fills the chip (profiles/r3_w32_ab_*.log); channel counts
-// that are not multiples of 128 would waste a third of a tile and grids below ~7/8 of the CUs (UNet planes, batch 1) are
-// better served by the 8x16 tiles of the halo conv.
+// tile == 0 routing: the wide tiles win on every VAE shape that fills the chip (profiles/r3_w32_ab_*.log: +20..24 % over
+// the halo conv with the GroupNorm prologue); channel counts that are not multiples of 128 would waste a third of a tile
+// and grids below ~7/8 of the CUs (UNet planes, batch 1) are better served by the 8x16 tiles of the halo conv.
 bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype) {
     if (!conv3x3_w32_eligible(p, dtype) || p.N % 128) return false;
     int th, bn, wtn;

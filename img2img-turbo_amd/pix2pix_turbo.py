@@ -148,7 +148,11 @@ class TurboGeneratorBase(torch.nn.Module):
                     pk.set_scale(r, r)
 
     def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1, u8_io=None) -> ForwardPlan:
-        self.set_lora_scale(float(r) if stochastic else 1.0)
+        """The cached plan for this shape.  `r` is not part of the key (device addresses do not depend on it): the plan
+        records the r of THIS request and re-applies it whenever it runs (ForwardPlan.before_run), so a caller may hold
+        several plans / r values and interleave their run() / replay()."""
+        r_plan = float(r) if stochastic else 1.0
+        self.set_lora_scale(r_plan)
         key = (B, H, W, self.dtype_, stochastic, direction, ctx_batch, u8_io)
         if key in self._plans:
             self._plans.move_to_end(key)
@@ -163,7 +167,13 @@ class TurboGeneratorBase(torch.nn.Module):
             while len(self._plans) > self.MAX_PLANS:      # LRU: the evicted plan's graph and activation pool are released
                 _, old = self._plans.popitem(last=False)
                 old.release()
-        return self._plans[key]
+        plan = self._plans[key]
+        plan.r = r_plan
+        plan.before_run = self._apply_plan_r
+        return plan
+
+    def _apply_plan_r(self, plan):
+        self.set_lora_scale(plan.r)
 
     def encode_prompt(self, prompt=None, prompt_tokens=None):
         """tokenizer(prompt, max_length=77, padding="max_length", truncation=True) -> text_encoder(ids)[0]

@@ -603,30 +603,51 @@ class ForwardPlan:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if torch.device(self.device).type == "cuda" else 0
 
+    # The LoRA scale / skip gamma / TwinConv fold `r` is DEVICE STATE of the model's packed weights, shared by every plan
+    # (packer.py).  A plan therefore records the r it was built for (`self.r`: the stochastic r, 1.0 for deterministic plans)
+    # and re-applies it through `before_run` (set by the owning model: Pix2Pix_Turbo.set_lora_scale) every time it executes:
+    # holding a stochastic and a deterministic plan, or two r values, and alternating run()/replay() is safe.  One model is
+    # single-stream with respect to r: the re-merge rewrites the weights in place on the current stream.
+    before_run = None
+    released = False
+
+    def _prepare(self):
+        if self.released:
+            raise RuntimeError("ForwardPlan was released (plan-cache eviction / dtype change): its buffers are gone; get a new plan")
+        if self.before_run is not None:
+            self.before_run(self)
+
     def run(self):
+        self._prepare()
         with self._on_device():
             self.lib.run(self.prog, self.stream())
 
     def capture(self):
+        if self.released:
+            raise RuntimeError("ForwardPlan was released: cannot capture a graph over freed buffers")
         if self.graph is None:
             with self._on_device():
                 self.graph = self.lib.graph_create(self.prog)
         return self.graph
 
     def replay(self):
+        self._prepare()
         with self._on_device():
             self.lib.graph_launch(self.capture(), self.stream())
 
     def run_timed(self):
+        self._prepare()
         with self._on_device():
             return self.lib.run_timed(self.prog, self.stream())
 
     def release(self):
-        """Destroy the captured hipGraph and drop the activation pool (plan-cache eviction)."""
+        """Destroy the captured hipGraph and drop the activation pool (plan-cache eviction).  The program's descriptors
+        still hold raw pointers into the freed tensors: the plan refuses to run afterwards."""
         if self.graph is not None:
             self.lib.graph_destroy(self.graph)
             self.graph = None
         self.pool.all.clear()
         self.pool.free_lists.clear()
         self._keep.clear()
+        self.released = True
 

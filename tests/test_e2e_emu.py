@@ -132,3 +132,30 @@ def test_buffer_recycling_is_invisible(emu_lib, monkeypatch):
     n_fresh = len(next(iter(fresh._plans.values())).pool.all)
     assert n_fresh > 2 * n_shared, (n_fresh, n_shared)          # the switch really removed the sharing
     assert torch.equal(a, b)
+
+
+@pytest.mark.slow
+def test_two_plans_with_different_r_interleave_and_released_plan_refuses(emu_lib):
+    """r (LoRA scale / skip gamma / TwinConv fold) is device state shared by every plan of a model.  A caller holding a
+    stochastic plan (r = 0.4) and a deterministic one and alternating stage() + run() -- what bench.py does with replay() --
+    gets each plan's own r: the plan re-applies it before it executes.  A released plan refuses to run."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib, use_graph=False)
+    ref_s = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=0.4, noise_map=nm)
+    ref_s7 = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=0.7, noise_map=nm)
+    ps = model.get_plan(1, 64, 64, stochastic=True, r=0.4)
+    for r_other, ref_other in ((0.7, ref_s7),):
+        model.get_plan(1, 64, 64, stochastic=True, r=r_other)         # same cached plan object, now requested at another r ...
+        assert model.get_plan(1, 64, 64, stochastic=True, r=r_other) is ps
+        model.stage(ps, x, cap, eps, nm)
+        ps.run()
+        assert (ps.out - ref_other).abs().max().item() < 1e-3
+    ps = model.get_plan(1, 64, 64, stochastic=True, r=0.4)            # ... and back
+    model.set_lora_scale(1.0)                                         # someone else moved the device state in between
+    model.stage(ps, x, cap, eps, nm)
+    ps.run()
+    assert (ps.out - ref_s).abs().max().item() < 1e-3
+    model.release_plans()
+    with pytest.raises(RuntimeError):
+        ps.run()

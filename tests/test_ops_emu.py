@@ -363,21 +363,16 @@ def test_image_prep_options_match_the_reference_transforms(emu_lib):
 W32_TILES = [41, 42]
 
 
-@pytest.mark.parametrize("lgroups", [None, "1"])
 @pytest.mark.parametrize("cfg", W32_TILES)
-def test_w32_conv_every_tile_config(emu_lib, cfg, lgroups, monkeypatch):
-    """32x32x16-MFMA wide-tile conv: GroupNorm+SiLU staged in the MFMA shadow, residual, ragged tiles in both plane
-    directions, two slabs (the halo stored after P_8), ragged channel tile (N = 136 on BN = 128 / 256).  lgroups = 1: one
-    workgroup per (XCD, channel tile), so every workgroup walks SEVERAL tiles -- the next tile's halo, GroupNorm constants
-    and weights are staged across the tile border, the epilogue's stores overlap the next tile, images change mid-stream."""
-    if lgroups:
-        monkeypatch.setenv("I2I_W32_LGROUPS", lgroups)
+def test_w32_conv_every_tile_config(emu_lib, cfg):
+    """32x32x16-MFMA wide-tile conv: GroupNorm+SiLU staged in the MFMA shadow, residual (staged through LDS in the row
+    layout), ragged tiles in both plane directions, two slabs (the halo stored after P_8), ragged channel tile (N = 136 on
+    BN = 128 / 256), channel tile by XCD with runs of unequal length (18 spatial tiles over 4 XCD groups)."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=3, cin=128, cout=256, h=20, w=72, gn=True, act=1, groups=8, res=True, tile=cfg)
     oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cin2=64, cout=136, h=33, w=65, tile=cfg, seed=3)
 
 
-def test_w32_conv_three_slabs_one_slab_and_route(emu_lib, monkeypatch):
-    monkeypatch.setenv("I2I_W32_LGROUPS", "1")
+def test_w32_conv_three_slabs_one_slab_and_route(emu_lib):
     """Three slabs over a concat seam, one-slab tiles (every slab is a tile's first and last), alpha; the route query names
     the kernel the dispatcher picks."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=128, h=16, w=32, gn=True, act=1, groups=8, tile=42)
@@ -396,12 +391,13 @@ def test_w32_conv_three_slabs_one_slab_and_route(emu_lib, monkeypatch):
     assert emu_lib.igemm_route(p3, K.F32) == "conv3x3_halo_kernel"          # exact-f32 parity mode stays on the halo kernel
 
 
-@pytest.mark.parametrize("lgroups", [None, "1"])
+@pytest.mark.parametrize("xcdtn", [None, "0"])
 @pytest.mark.parametrize("cfg", [41, 42])
-def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, lgroups, monkeypatch):
-    """The epilogue's GroupNorm partial sums of the STORED output (one slot per tile and group), finished by gn_stats."""
-    if lgroups:
-        monkeypatch.setenv("I2I_W32_LGROUPS", lgroups)
+def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, xcdtn, monkeypatch):
+    """The epilogue's GroupNorm partial sums of the STORED output (v_dot2c per channel quad; one slot per tile and group),
+    finished by gn_stats.  xcdtn = 0: the tile order without the channel-tile-per-XCD rule."""
+    if xcdtn:
+        monkeypatch.setenv("I2I_W32_XCDTN", xcdtn)
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=64, groups=32, tile=cfg)      # cpg 8
     oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=20, w=40, groups=32, tile=cfg, res=False)   # cpg 4, ragged tiles
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=512, h=8, w=32, groups=32, tile=cfg)       # cpg 16

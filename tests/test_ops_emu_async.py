@@ -28,7 +28,6 @@ def test_w32_conv_waits_and_barriers(async_lib, cfg, order, monkeypatch):
     barrier that publishes the halo stored after P_8, on the latest-completion memory model with run-ahead wave orders."""
     if order is not None:
         monkeypatch.setenv("I2I_EMU_ORDER", order)
-    monkeypatch.setenv("I2I_W32_LGROUPS", "1")            # several tiles per workgroup: the waits at and after a tile border
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=192, cout=136, h=18, w=72, gn=True, act=1, res=True, tile=cfg)   # 3 slabs, ragged tiles
     oc.check_conv_gn_part(async_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=16, w=32, groups=32, tile=cfg)
 
