@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 F_ALG = {512: 4.477e12, 1024: 20.22e12}   # algorithmic FLOP / image
 PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 CPU_BASELINE_THREADS = 16
+CPU_BASELINE_TIMED = 2        # + 1 warm-up: ~30 s of CPU work in the default run
 PER_OP_PATH = None
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_conv3x3_halo.json")   # tools/pmc_traffic.py, PMC passes of THIS command
@@ -123,16 +124,24 @@ def cpu_baseline(a, weights, x, cap, eps, noise):
     # oneDNN/OpenMP oversubscribe badly past a few dozen threads on these shapes (256 threads: 488 s for one
     # forward on the 256-core GPU box, 8 threads: 32 s): cap the pool and report the cap as `cores`
     torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
-    t0 = time.time()
-    if a.model == "cyclegan":
-        out = cyclegan_forward(mw, x[:1], cap, eps[:1], direction=a.direction)
-    elif a.stochastic:
-        out = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=a.gamma, noise_map=noise[:1])
-    else:
-        out = pix2pix_forward(mw, x[:1], cap, eps[:1])
-    dt = time.time() - t0
+
+    def fwd():
+        if a.model == "cyclegan":
+            return cyclegan_forward(mw, x[:1], cap, eps[:1], direction=a.direction)
+        if a.stochastic:
+            return pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=a.gamma, noise_map=noise[:1])
+        return pix2pix_forward(mw, x[:1], cap, eps[:1])
+
+    out = fwd()                         # warm-up (oneDNN primitive creation, page faults)
+    times = []
+    for _ in range(CPU_BASELINE_TIMED):
+        t0 = time.time()
+        out = fwd()
+        times.append(time.time() - t0)
+    dt = statistics.median(times)
     return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 sample: image 0 of the batch (%dx%d), fp32, unmerged LoRA, one un-warmed forward (%.1f s)" % (a.size, a.size, dt)}, out
+            "sample": "image 0 of the batch (%dx%d), fp32, unmerged LoRA: 1 warm-up + %d timed forwards, median %.1f s (host has %d cores; "
+                      "more threads are slower on these shapes)" % (a.size, a.size, CPU_BASELINE_TIMED, dt, os.cpu_count() or 0)}, out
 
 
 def free_port():
@@ -191,7 +200,12 @@ def main():
     B = a.batch
     total = B * world
 
-    # random init of the exact architecture (no checkpoints offline); every rank builds the same weights, its own images
+    # random init of the exact architecture (no checkpoints offline); every rank builds the same weights, its own images.
+    # N ranks build and pack ~950 M synthetic parameters on the host at the same time: each gets its share of the cores
+    # (unconstrained they oversubscribe each other), and the set-up time is reported per rank next to the timed region.
+    t_setup = time.perf_counter()
+    if world > 1:
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if a.model == "cyclegan":
         weights = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
         model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype)
@@ -207,6 +221,8 @@ def main():
         plan = model.get_plan(B, a.size, a.size, stochastic=a.stochastic, r=a.gamma)
     model.stage(plan, x.to(dev), cap.to(dev), eps.to(dev), noise.to(dev) if a.stochastic else None)
     gather = dp.OutputGather(plan.out, total) if (world > 1 and not a.no_gather) else None
+    torch.cuda.synchronize()
+    setup_s = dp.all_ranks(time.perf_counter() - t_setup, dev)
 
     def step():
         plan.replay()
@@ -225,6 +241,16 @@ def main():
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = elapsed / a.steps * 1e3
     value = total * a.steps / elapsed
+    ms_compute = None
+    if world > 1:
+        # attribution of a scaling shortfall (outside the timed region): the same steps without the gather, per rank
+        dp.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            plan.replay()
+        torch.cuda.synchronize()
+        ms_compute = [round(v / a.steps * 1e3, 3) for v in dp.all_ranks(time.perf_counter() - t1, dev)]
 
     if rank != 0:
         return
@@ -239,6 +265,10 @@ def main():
                       "global_batch": total, "parallelism": "dp%d (batch shards, replicated weights, RCCL gather of outputs)" % world,
                       "arch": a.arch, "kernel_library": os.path.basename(model.lib.path)},
            "baseline_note": "vs_baseline = value / 9.09 img/s (0.11 s per 512x512 image on A100, reference README.md:17)"}
+    if world > 1:
+        rec["ms_compute_per_rank"] = ms_compute                     # replay only (no gather), measured after the timed region
+        rec["ms_gather"] = round(ms_per_step - max(ms_compute), 3)   # what the RCCL gather adds to the slowest rank's step
+        rec["setup_s_per_rank"] = [round(v, 1) for v in setup_s]      # weights built + packed + uploaded + plan, concurrently on the host
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":
         rec["e2e_mfma_frac"] = round(value / world * falg / 1e12 / PEAK_TF[a.dtype], 4)

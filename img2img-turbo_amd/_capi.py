@@ -66,7 +66,7 @@ class EmbedParams(C.Structure):
 
 class NchwToNhwcParams(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("n", i32), ("c", i32), ("h", i32), ("w", i32), ("cpad", i32),
-                ("src_dtype", i32), ("mul", f32), ("add", f32)]
+                ("src_dtype", i32), ("mul", f32), ("add", f32), ("binarize_below", i32)]
 
 
 class NhwcToNchwParams(C.Structure):

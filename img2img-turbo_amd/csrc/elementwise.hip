@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void u8hwc_to_nhwc_kernel(const i2i_nchw_to_nh
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const uint8_t* x = (const uint8_t*)p.x + i * p.c;
         T* y = (T*)p.y + i * p.cpad;
-        for (int c = 0; c < p.cpad; ++c) y[c] = (c < p.c) ? from_f32<T>((float)x[c] * k + p.add) : from_f32<T>(0.f);
+        for (int c = 0; c < p.cpad; ++c) {
+            float v = 0.f;
+            if (c < p.c) v = p.binarize_below > 0 ? ((int)x[c] < p.binarize_below ? p.mul + p.add : p.add) : (float)x[c] * k + p.add;
+            y[c] = from_f32<T>(v);
+        }
     }
 }
 // NHWC `T` -> uint8 HWC: clamp, x*mul+add, ToPILImage's mul(255).byte() (truncation)

@@ -91,6 +91,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def all_ranks(value, device):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one small all_gather)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -128,11 +128,13 @@ def embed(ids, tok, pos, y, *, rows, T, c):
     return K.OP_EMBED, _keep(p, ids, tok, pos, y)
 
 
-def nchw_to_nhwc(x, y, *, n, c, h, w, cpad, mul=1.0, add=0.0):
-    """x: NCHW float tensor, or a uint8 HWC image batch [n, h, w, c] (then y = x/255*mul + add)."""
+def nchw_to_nhwc(x, y, *, n, c, h, w, cpad, mul=1.0, add=0.0, binarize_below=0):
+    """x: NCHW float tensor, or a uint8 HWC image batch [n, h, w, c] (then y = x/255*mul + add, or with binarize_below = k:
+    y = (x < k)*mul + add -- the sketch script's ``F.to_tensor(img) < 0.5`` is k = 128)."""
     p = K.NchwToNhwcParams()
     p.x, p.y, p.n, p.c, p.h, p.w, p.cpad = ptr(x), ptr(y), n, c, h, w, cpad
     p.src_dtype, p.mul, p.add = (K.U8 if x.dtype == torch.uint8 else DT[x.dtype]), mul, add
+    p.binarize_below = int(binarize_below)
     return K.OP_NCHW_TO_NHWC, p
 
 

@@ -235,17 +235,19 @@ class Pix2Pix_Turbo(TurboGeneratorBase):
             self.lora_rank_unet, self.lora_rank_vae = weights.meta["rank_unet"], weights.meta["rank_vae"]
 
     @torch.no_grad()
-    def forward_u8(self, images_u8, *args, resize=None, **kw):
+    def forward_u8(self, images_u8, *args, resize=None, sketch=False, **kw):
         """uint8 HWC in, uint8 HWC out ([B, H, W, 3] on the device): the callers' ``F.to_tensor`` (src/inference_paired.py:50)
         and ``ToPILImage()(out*0.5+0.5)`` (:72) run inside the boundary kernels; everything else as ``forward``.
         ``resize="multiple_of_8"`` first applies the script's ``input_image.resize((w - w % 8, h - h % 8), Image.LANCZOS)``
-        (:38-41) on the device, bit-identical to Pillow (image_ops.lanczos_resize_u8); ``resize=(width, height)`` any size."""
+        (:38-41) on the device, bit-identical to Pillow (image_ops.lanczos_resize_u8); ``resize=(width, height)`` any size.
+        ``sketch=True``: the sketch branch's binarisation ``F.to_tensor(input_image) < 0.5`` (:57-58) instead of ``to_tensor``
+        (bytes below 128 become 1.0, the others 0.0), as the stochastic sketch model expects."""
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
         if resize is not None:
             from .image_ops import lanczos_resize_u8, resize_to_multiple_of_8
             with self._on_device():
                 images_u8 = resize_to_multiple_of_8(images_u8, self.lib) if resize == "multiple_of_8" else lanczos_resize_u8(images_u8, resize, self.lib)
-        return self.forward(images_u8, *args, _u8_io=(1.0, 0.0), **kw)
+        return self.forward(images_u8, *args, _u8_io=(1.0, 0.0, 128) if sketch else (1.0, 0.0), **kw)
 
     @torch.no_grad()
     def forward(self, c_t, prompt=None, prompt_tokens=None, deterministic=True, r=1.0, noise_map=None,

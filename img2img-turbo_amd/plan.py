@@ -567,8 +567,8 @@ class ForwardPlan:
         h8, w8 = H // 8, W // 8
         self._zero_init = []
         x = self.new(B, H, W, 8)
-        mul, add = self.u8_io if self.u8_io else (1.0, 0.0)
-        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8, mul=mul, add=add), "input.to_nhwc")
+        mul, add, thr = (tuple(self.u8_io) + (0,))[:3] if self.u8_io else (1.0, 0.0, 0)      # (mul, add[, binarize_below])
+        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8, mul=mul, add=add, binarize_below=thr), "input.to_nhwc")
         moments, skips = self._vae_encoder(x)
         # x (= conv_in input) is not a skip; skips[0] is conv_in's output
         self.free(x)

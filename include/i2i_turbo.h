@@ -156,10 +156,12 @@ typedef struct {
  * With src_dtype / dst_dtype = I2I_U8 the outer tensor is a uint8 image batch [n][h][w][c] (HWC, as PIL / numpy hand
  * it over) and the callers' pre/post-processing is folded in:
  *   in : y = u8/255 * mul + add     (F.to_tensor, src/inference_paired.py:50; Normalize([0.5],[0.5]) = mul 2, add -1,
- *                                     src/inference_unpaired.py:47)
+ *                                     src/inference_unpaired.py:47); with binarize_below: the sketch threshold, see the struct
  *   out: u8 = trunc(clamp01(v*mul + add) * 255)   (ToPILImage()(x*0.5+0.5) = mul .5, add .5: src/inference_paired.py:72) */
 typedef struct {
     const void* x; void* y; int32_t n, c, h, w, cpad; int32_t src_dtype; float mul, add;
+    int32_t binarize_below;    /* I2I_U8 sources only, 0 = off: v = (u8 < binarize_below) ? 1 : 0 instead of u8/255, then v*mul + add.
+                                  128 = the sketch script's `F.to_tensor(image) < 0.5` (src/inference_paired.py:57-58: 127/255 < 0.5 <= 128/255) */
 } i2i_nchw_to_nhwc_params;
 typedef struct {
     const void* x; void* y; int32_t n, c, h, w, ldx; int32_t dst_dtype; int32_t clamp; /* clamp to [-1,1] */

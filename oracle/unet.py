@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from .arch import UNetArch
-from .nn import (Weights, conv2d, group_norm, resnet_block, timestep_embedding,
+from .nn import (Weights, conv2d, group_norm, q, resnet_block, timestep_embedding,
                  transformer_2d)
 
 
@@ -27,7 +27,7 @@ def conv_in(W: Weights, x, twin_r=None):
             raise ValueError("TwinConv conv_in needs r (reference crashes with r=None, A.9 quirk 5)")
         x1 = conv2d(W, "conv_in.conv_in_pretrained", x, padding=1)
         x2 = conv2d(W, "conv_in.conv_in_curr", x, padding=1)
-        return x1 * (1 - twin_r) + x2 * twin_r
+        return q(x1 * (1 - twin_r) + x2 * twin_r)
     return conv2d(W, "conv_in", x, padding=1)
 
 
@@ -72,5 +72,5 @@ def unet_forward(W: Weights, arch: UNetArch, x, ctx, twin_r=None, t=None):
                 else F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = conv2d(W, f"up_blocks.{i}.upsamplers.0.conv", h, padding=1)
     assert not res
-    h = F.silu(group_norm(W, "conv_norm_out", h, g, eps))
+    h = q(F.silu(group_norm(W, "conv_norm_out", h, g, eps)))
     return conv2d(W, "conv_out", h, padding=1)

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from .arch import VAEArch
-from .nn import Weights, conv2d, group_norm, resnet_block, vae_attention
+from .nn import Weights, conv2d, group_norm, q, resnet_block, vae_attention
 
 
 def encoder_forward(W: Weights, arch: VAEArch, x):
@@ -27,7 +27,7 @@ def encoder_forward(W: Weights, arch: VAEArch, x):
     h = resnet_block(W, "encoder.mid_block.resnets.0", h, g, eps)
     h = vae_attention(W, "encoder.mid_block.attentions.0", h, g, eps)
     h = resnet_block(W, "encoder.mid_block.resnets.1", h, g, eps)
-    h = F.silu(group_norm(W, "encoder.conv_norm_out", h, g, eps))
+    h = q(F.silu(group_norm(W, "encoder.conv_norm_out", h, g, eps)))
     h = conv2d(W, "encoder.conv_out", h, padding=1)
     return conv2d(W, "quant_conv", h), skips
 
@@ -50,11 +50,11 @@ def decoder_forward(W: Weights, arch: VAEArch, z, skips, gamma=1.0):
     nb = len(arch.block_out_channels)
     for i in range(nb):
         if skips is not None:  # ignore_skip == False
-            h = h + conv2d(W, f"decoder.skip_conv_{i + 1}", skips[::-1][i] * gamma)
+            h = q(h + conv2d(W, f"decoder.skip_conv_{i + 1}", q(skips[::-1][i] * gamma)))
         for j in range(arch.layers_per_block + 1):
             h = resnet_block(W, f"decoder.up_blocks.{i}.resnets.{j}", h, g, eps)
         if i < nb - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = conv2d(W, f"decoder.up_blocks.{i}.upsamplers.0.conv", h, padding=1)
-    h = F.silu(group_norm(W, "decoder.conv_norm_out", h, g, eps))
+    h = q(F.silu(group_norm(W, "decoder.conv_norm_out", h, g, eps)))
     return conv2d(W, "decoder.conv_out", h, padding=1)

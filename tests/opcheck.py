@@ -359,6 +359,13 @@ def check_u8_boundary(lib, device, dtype, *, n=2, h=6, w=10, seed=0):
     got = y.cpu().float()
     assert (got[..., 3:] == 0).all()
     assert (got[..., :3] - ref.to(dtype).float()).abs().max() <= (1e-6 if dtype == torch.float32 else 8e-3)
+    # the sketch script's binarisation F.to_tensor(img) < 0.5 (src/inference_paired.py:57-58): exact, every byte value
+    ramp = torch.arange(256, dtype=torch.uint8).repeat(n * h * w * 3 // 256 + 1)[: n * h * w * 3].reshape(n, h, w, 3).contiguous()
+    rampd = ramp.to(device)
+    yb = torch.full((n, h, w, 8), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.nchw_to_nhwc(rampd, yb, n=n, c=3, h=h, w=w, cpad=8, binarize_below=128)
+    run_op(lib, opcode, p, dtype, device)
+    assert torch.equal(yb.cpu().float()[..., :3], ((ramp.float() / 255.0) < 0.5).float()) and (yb.cpu().float()[..., 3:] == 0).all()
     # output side: values on an exact 1/255 grid survive the round trip bit for bit in fp32
     x = torch.zeros(n, h, w, 8)
     x[..., :3] = ref

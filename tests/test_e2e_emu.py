@@ -101,6 +101,22 @@ def test_pix2pix_u8_io_matches_float_io(emu_lib):
 
 
 @pytest.mark.slow
+def test_sketch_u8_binarisation_matches_the_script(emu_lib):
+    """src/inference_paired.py:57-66 (sketch_to_image_stochastic branch): ``c_t = (F.to_tensor(img) < 0.5).float()`` then the
+    stochastic forward.  forward_u8(..., sketch=True) does the threshold inside the uint8 boundary kernel."""
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
+    _, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (1, 64, 64, 3), generator=g, dtype=torch.uint8)          # a grey-level "sketch"
+    c_t = ((img.permute(0, 3, 1, 2).float() / 255.0) < 0.5).float()
+    ref = pix2pix_forward(mw, c_t, cap, eps, deterministic=False, r=0.4, noise_map=nm)
+    model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
+    out = model.forward_u8(img, caption_enc=cap, eps=eps, deterministic=False, r=0.4, noise_map=nm, sketch=True)
+    exp = ((ref.clamp(-1, 1) * 0.5 + 0.5).clamp(0, 1) * 255.0).to(torch.uint8).permute(0, 2, 3, 1)
+    assert (out.int() - exp.int()).abs().max().item() <= 1
+
+
+@pytest.mark.slow
 def test_pix2pix_odd_latent_size_fp32(emu_lib):
     """72 x 88 input (multiples of 8, not of 64): latent 9 x 11, UNet levels 9x11 -> 5x6 -> 3x3 -> 2x2 with explicit
     upsample sizes (row f3; the reference resizes to multiples of 8 only: src/inference_paired.py:38-41)."""

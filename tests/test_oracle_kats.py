@@ -202,3 +202,21 @@ def test_lanczos_resize_oracle_is_pinned_against_pillow():
             a[: h // 2] = (a[: h // 2] > 127) * 255          # hard edges: negative lobes and clipping at 0 / 255
         ref = np.asarray(Image.fromarray(a, "RGB").resize((ow, oh), Image.LANCZOS))
         assert np.array_equal(lanczos_resize_u8(a, ow, oh), ref), (h, w, oh, ow)
+
+
+def test_emulated_precision_mode_is_a_floor_and_leaves_fp32_alone():
+    """oracle/nn.py `quantized(dtype)`: rounds weights and layer outputs to the dtype with fp32 accumulation.  Outside the
+    context the fp32 oracle is bit-identical to before; inside, the distance from fp32 is the dtype's floor on this input:
+    non-zero, finite, and an order of magnitude smaller for fp16 (11-bit significand) than for bf16 (8-bit)."""
+    from oracle.nn import quantized
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    errs = {}
+    for dt in (torch.bfloat16, torch.float16):
+        with quantized(dt):
+            o = pix2pix_forward(mw, x, cap, eps)
+        assert torch.isfinite(o).all()
+        errs[dt] = (o - ref).pow(2).mean().sqrt().item()
+    assert torch.equal(pix2pix_forward(mw, x, cap, eps), ref)
+    assert 0 < errs[torch.float16] < 0.25 * errs[torch.bfloat16] < 0.02
