@@ -94,9 +94,41 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const i2i_gn_stats_para
     }
 }
 
+// ---- second pass for groups whose one-pass variance cannot be trusted.  E[x^2] - mu^2 in fp32 loses log2(mu^2/var) bits to
+// cancellation on top of the rounding the long sums already carry: with |mean| > 16 sigma the relative error of the variance
+// passes ~1e-3 (F.group_norm is two-pass / Welford; real SD-VAE decoder activations do sit on large DC offsets).  Those
+// groups -- and only those: the decision is a deterministic function of the first pass -- are re-read by the whole block
+// against the first-pass mean: mu' = mu + E[x - mu], var' = E[(x - mu)^2] - E[x - mu]^2, exact to fp32 round-off.  Needs the
+// tensor (p.x0 / p.x1), also in finalize_only mode; without it (x0 == NULL) the one-pass numbers stand.
+constexpr float GN_REFINE_RATIO = 256.f;          // refine when var * 256 < mu^2
+template <typename T>
+__device__ void gn_refine_group(const i2i_gn_stats_params& p, int img, int g, float* red /* >= 512 floats of LDS */, float& mu, float& var) {
+    const int tid = threadIdx.x, ct = p.c0 + p.c1, cpg = ct / p.groups;
+    float s1 = 0.f, s2 = 0.f;
+    for (int px = tid; px < p.hw; px += 256)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const T* src = (c < p.c0) ? (const T*)p.x0 + ((int64_t)img * p.hw + px) * p.ld0 + c
+                                      : (const T*)p.x1 + ((int64_t)img * p.hw + px) * p.ld1 + (c - p.c0);
+            const float d = to_f32<T>(*src) - mu;
+            s1 += d;
+            s2 += d * d;
+        }
+    __syncthreads();
+    red[2 * tid] = s1;
+    red[2 * tid + 1] = s2;
+    __syncthreads();
+    float S1 = 0.f, S2 = 0.f;
+    for (int k = 0; k < 256; ++k) { S1 += red[2 * k]; S2 += red[2 * k + 1]; }      // every thread, fixed order: deterministic, uniform result
+    const float inv = 1.0f / ((float)cpg * (float)p.hw), m1 = S1 * inv;
+    mu += m1;
+    var = fmaxf(S2 * inv - m1 * m1, 0.f);
+    __syncthreads();
+}
+
 // grid = (nimg, groups / gpb): a block finishes gpb groups of one image.  Each group's part range is cut into
 // 256 / gpb slices (conv epilogues hand over thousands of parts) that are combined in a fixed order afterwards,
 // so the result does not depend on scheduling.
+template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_params p, int gpb) {
     const int tid = threadIdx.x, img = blockIdx.x, g0 = blockIdx.y * gpb;
     const int ct = p.c0 + p.c1, cpg = ct / p.groups;
@@ -125,7 +157,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
         const float mu = S * inv;
         const float var = fmaxf(Q * inv - mu * mu, 0.f);
         mean[tid] = mu;
-        rstd[tid] = rsqrtf(var + p.eps);
+        rstd[tid] = var;          // variance for now: the refinement below may replace it
+    }
+    __syncthreads();
+    for (int g = 0; g < gpb; ++g) {                // uniform over the block
+        float mu = mean[g], var = rstd[g];
+        if (p.x0 && var * GN_REFINE_RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
+        __syncthreads();
+        if (tid == 0) { mean[g] = mu; rstd[g] = rsqrtf(var + p.eps); }
     }
     __syncthreads();
     for (int c = g0 * cpg + tid; c < (g0 + gpb) * cpg; c += 256) {
@@ -301,7 +340,14 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
         const float mu = S * inv;
         const float var = fmaxf(Q * inv - mu * mu, 0.f);
         gst[2 * tid] = mu;
-        gst[2 * tid + 1] = rsqrtf(var + p.eps);
+        gst[2 * tid + 1] = var;   // variance for now: the refinement below may replace it
+    }
+    __syncthreads();
+    for (int g = 0; g < gpb; ++g) {                // uniform over the block
+        float mu = gst[2 * g], var = gst[2 * g + 1];
+        if (var * GN_REFINE_RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
+        __syncthreads();
+        if (tid == 0) { gst[2 * g] = mu; gst[2 * g + 1] = rsqrtf(var + p.eps); }
     }
     __syncthreads();
     for (int c = tid; c < nch; c += 256) {
@@ -387,7 +433,9 @@ int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
     // a shorter serial chain per thread (8 parts instead of 64); the summation order stays a function of the shape only
     if (p.nparts >= 1024) gpb = 1;
     else if (p.nparts >= 256 && p.groups % 2 == 0) gpb = 2;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256), (size_t)gpb * 8 + (size_t)(256 / gpb) * gpb * 8, s, p, gpb);
+    const size_t red_bytes = (size_t)(256 / gpb) * gpb * 8;
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256),
+                       (size_t)gpb * 8 + (red_bytes < 4096 ? 4096 : red_bytes), s, p, gpb);
     return i2i::check_launch("gn_finalize");
 }
 

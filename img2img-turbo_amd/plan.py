@@ -174,7 +174,8 @@ class ForwardPlan:
                 self._keep.append(part)
                 x.producer.gn_part, x.producer.gn_part_groups = part.data_ptr(), groups
                 self._gn_scratch(x.n, ct, 1, groups)
-                op = O.gn_stats(None, gamma, beta, part, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=parts,
+                # (the tensor still rides along: groups whose one-pass variance is cancellation-prone are re-read, csrc/norm.hip)
+                op = O.gn_stats(x.t, gamma, beta, part, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=parts,
                                 c0=x.c, ld0=x.c, finalize_only=1)
                 self._pending_gn.append((op[1], "stats_ss"))
                 self._add(op, (label or norm_name) + ".finalize")

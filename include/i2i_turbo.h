@@ -108,14 +108,17 @@ typedef struct {
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.
  * Replaces the reduction half of F.group_norm; the affine+SiLU half runs in the consumer's prologue.
- * Two-stage and atomics-free (deterministic).  `partial` needs nimg*nparts*groups*2 floats. */
+ * Two-stage and atomics-free (deterministic).  One-pass sums (sum, sum of squares) in fp32 with a second, shifted pass over
+ * exactly the groups where |mean| > 16 sigma (F.group_norm is two-pass; DESIGN.md "Numerics").  `partial` needs nimg*nparts*groups*2 floats. */
 typedef struct {
     const void* x0; const void* x1; int32_t c0, c1, ld0, ld1;
     int32_t nimg, hw, groups; float eps;
     const float* gamma; const float* beta;    /* [c0+c1] fp32 */
     float* partial; int32_t nparts;
     float* ss;                                /* out [nimg][c0+c1][2] */
-    int32_t finalize_only;                    /* 1: `partial` was produced by a conv epilogue (gn_part); x0 unused */
+    int32_t finalize_only;                    /* 1: `partial` was produced by a conv epilogue (gn_part).  x0 (+ ld0) may still be
+                                                 given: groups whose one-pass variance is below mean^2 / 256 (cancellation) are
+                                                 then re-read against the first-pass mean; with x0 = NULL the one-pass numbers stand */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its

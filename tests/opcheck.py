@@ -191,6 +191,43 @@ def check_gn_stats(lib, device, dtype, *, n=2, c0=32, c1=0, h=9, w=7, groups=8, 
     return err
 
 
+def check_gn_stats_offset(lib, device, dtype, *, n=2, c=32, h=48, w=40, groups=8, nparts=3, mean=100.0, std=0.1, seed=0, finalize_only=False):
+    """GroupNorm statistics of a tensor sitting on a large offset (|mean| = 1000 sigma): E[x^2] - mu^2 in fp32 would return
+    noise for the variance; the second, shifted pass over the flagged groups must bring x*scale + shift within 1e-3 of
+    F.group_norm (which is two-pass).  Channels get different offsets so that groups differ.  finalize_only: the partial sums
+    are handed over as a conv epilogue would (one-pass (sum, sum of squares) per part), the tensor rides along."""
+    g = torch.Generator().manual_seed(seed)
+    base = mean * (1 + 0.05 * torch.arange(groups).float()).repeat_interleave(c // groups)
+    x = torch.randn(n, c, h, w, generator=g) * std + base[None, :, None, None]
+    gamma = 1 + 0.1 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    xq = x.to(dtype).float()
+    ref = F.group_norm(xq.double(), groups, gamma.double(), beta.double(), 1e-5).float()
+    x0 = nhwc(x, dtype).to(device)
+    ss = torch.full((n, c, 2), float("nan"), device=device)
+    if finalize_only:
+        cpg = c // groups
+        xs = xq.reshape(n, groups, cpg, h * w)
+        per = -(-(h * w) // nparts)
+        parts = torch.zeros(n, nparts, groups, 2)
+        for k in range(nparts):
+            sl = xs[..., k * per:(k + 1) * per]
+            parts[:, k, :, 0] = sl.sum((-1, -2))
+            parts[:, k, :, 1] = (sl * sl).sum((-1, -2))
+        partial = parts.reshape(-1).contiguous().to(device)
+    else:
+        partial = torch.zeros(n * nparts * groups * 2, device=device)
+    opcode, p = O.gn_stats(x0, gamma.to(device), beta.to(device), partial, ss, nimg=n, hw=h * w, groups=groups, eps=1e-5,
+                           nparts=nparts, c0=c, finalize_only=1 if finalize_only else 0)
+    run_op(lib, opcode, p, dtype, device)
+    sc = ss.cpu()
+    y = xq * sc[:, :, 0][:, :, None, None] + sc[:, :, 1][:, :, None, None]
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert torch.isfinite(y).all() and err < 1e-3 * max(scale, 1.0), f"gn_stats with offset: max-abs {err} (outputs up to {scale})"
+    return err
+
+
 def check_layernorm(lib, device, dtype, *, rows=9, c=320, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(rows, c, generator=g) * 2 + 0.5

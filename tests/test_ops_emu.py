@@ -272,6 +272,14 @@ def test_dma_igemm_epilogue_groupnorm_partials(emu_lib, wgs, monkeypatch):
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=64, h=32, w=32, groups=8, tile=20, stride=2)          # stride-2 gather
 
 
+def test_gn_stats_large_offset_second_pass(emu_lib):
+    """|mean| = 1000 sigma: the one-pass variance is noise; the flagged groups are re-read against the first-pass mean
+    (single-launch kernel, partial + finalize pair, and finalize over conv-epilogue style one-pass partials)."""
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, h=24, w=20)                             # single launch (small tensor)
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, h=24, w=20, finalize_only=True, nparts=7)
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, c=24, groups=3, h=10, w=12, mean=-40.0, std=0.05)   # odd group count, negative offset
+
+
 def test_gn_finalize_many_parts(emu_lib):
     """Finalize with hundreds / thousands of parts per image (what 512x512 conv epilogues hand over): the launcher
     switches to 2 and then 1 group per block."""

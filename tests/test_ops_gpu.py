@@ -230,3 +230,13 @@ def test_w32_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=1, cin=64, cout=128, h=40, w=72, groups=32, tile=cfg, res=False)
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=8, cin=128, cout=128, h=64, w=128, groups=32, tile=0)      # auto route: 8 x 4 x 4 = 128 ... halo
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=8, cin=64, cout=128, h=128, w=128, groups=32, tile=0)      # auto route: 256 wide tiles
+
+
+@pytest.mark.gpu
+def test_gn_stats_large_offset_second_pass(gpu_lib):
+    """GroupNorm statistics with |mean| = 1000 sigma vs F.group_norm (two-pass): <= 1e-3 on the normalised output in fp32,
+    through all three routes (single launch, partial + finalize, finalize over one-pass conv-epilogue partials)."""
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=64, w=64, groups=32)                      # single launch
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=256, w=256, groups=32, nparts=64)         # partial + finalize
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=128, w=128, groups=32, nparts=512, finalize_only=True)
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=1, c=256, h=64, w=64, groups=32, mean=-30.0, std=0.02, nparts=16, finalize_only=True)
