@@ -6,14 +6,14 @@
 #   3. HBM traffic of the halo conv launches: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), corrected per
 #      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3_halo.json keyed on the kernel-source hash
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
-TAG=${1:-r2}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
+TAG=${1:-r3}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
 cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
 F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/${TAG}_write -name "*counter_collection.csv" | head -1)
-python tools/pmc_traffic.py $F $W conv3x3_halo_kernel --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
+python tools/pmc_traffic.py $F $W conv3x3_ --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
     --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3_halo.json
 cp $O/${TAG}_traffic_conv3x3_halo.json profiles/traffic_conv3x3_halo.json
 python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
@@ -38,5 +38,5 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_tr
 cp $(find $O/${TAG}_trace_bs1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs1_kernel_stats.csv
 # 6. SQ counters of the halo conv on its two characteristic shapes (one counter set per pass)
 timeout 600 bash benchmarks/pmc_conv.sh $O/${TAG}_pmc "vae 128->128@512 gn,vae 512->512@128 gn" > /dev/null 2>&1
-python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc/sq2 -name "*counter_collection.csv" | head -1) conv3x3_halo_kernel > $O/${TAG}_pmc_conv3x3_halo_summary.txt 2>&1
-cat $O/${TAG}_pmc_conv3x3_halo_summary.txt
+python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc/sq2 -name "*counter_collection.csv" | head -1) conv3x3_ > $O/${TAG}_pmc_conv3x3_summary.txt 2>&1
+cat $O/${TAG}_pmc_conv3x3_summary.txt

@@ -299,6 +299,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     if (p.bias_mode && !p.bias) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bias_mode without bias");
     if (p.geglu && (p.N % 32 || p.out_f32 || p.bias_mode == 2)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad geglu config");
     if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b) & 15) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: operands must be 16-byte aligned");
+    // the conv kernels bring the tile's bias vector into LDS by 16-byte DMA pieces
+    if (p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bias must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather

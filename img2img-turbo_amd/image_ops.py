@@ -61,14 +61,21 @@ def lanczos_coeffs(in_size, out_size):
     return ksize, bounds, ik
 
 
-_DEV_TABLES = {}
+import collections
+
+_DEV_TABLES = collections.OrderedDict()      # (in, out, device) -> coefficient tables on the device; small LRU: a server fed
+_DEV_TABLES_MAX = 64                         # arbitrary input sizes must not grow device memory without bound
 
 
 def _tables(in_size, out_size, device):
     key = (in_size, out_size, str(device))
-    if key not in _DEV_TABLES:
+    if key in _DEV_TABLES:
+        _DEV_TABLES.move_to_end(key)
+    else:
         ksize, b, k = lanczos_coeffs(in_size, out_size)
         _DEV_TABLES[key] = (ksize, torch.from_numpy(b.copy()).to(device), torch.from_numpy(k.copy()).to(device))
+        while len(_DEV_TABLES) > _DEV_TABLES_MAX:
+            _DEV_TABLES.popitem(last=False)
     return _DEV_TABLES[key]
 
 

@@ -173,7 +173,7 @@ class Packer:
     def conv(self, name, split=None, extra_bias=None, gamma=False):
         """-> dict(w=[N][K] dtype, b=fp32 or None, n=N, ks=k).  ``split``: channel count of concat source 0;
         ``gamma``: the skip-conv weights carry the decoder's skip gamma (src/model.py:41-43)."""
-        key = ("conv", name, split)
+        key = ("conv", name, split, bool(gamma), extra_bias is not None)     # a second call with other flags must not get the first packing
         if key not in self.cache:
             w, b = self.base(name)
             ab = self.lora(name)
