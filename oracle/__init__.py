@@ -37,7 +37,14 @@ The way to a pin for the VAE / UNet path exists but cannot be walked here:
 tests/golden/make_reference_golden.py instantiates the reference's OWN classes
 on the CPU (patched ``from_pretrained`` / ``.cuda()``) where diffusers + peft are
 importable and writes fixtures that test_oracle_matches_reference_golden
-consumes.
+consumes.  Round 3 probed the GPU box for them as well (``python -c 'import
+diffusers, peft'`` inside a gpurun call): ``ModuleNotFoundError: No module named
+'diffusers'`` -- same image, same answer; the pin stays open.
+
+Precision modes: ``oracle.nn.quantized(dtype)`` makes the same forward round to
+bf16 / fp16 wherever the device stores an activation or reads a 16-bit weight
+(fp32 accumulation, statistics and latents): the error floor of the dtype that
+the HIP path's 16-bit gates are measured against.
 """
 
 from .arch import VAEArch, UNetArch, SD_TURBO_VAE, SD_TURBO_UNET, TINY_VAE, TINY_UNET  # noqa: F401
