@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--lib", default=None, help="alternate build of the library (ablation experiments)")
     ap.add_argument("--splitk", default="0", help="comma list of split-K factors to try (LDS-DMA igemm)")
     ap.add_argument("--trace", action="store_true", help="library built with -DI2I_TRACE=1: print the per-segment cycle split of the halo conv")
+    ap.add_argument("--res", action="store_true", help="add a residual tensor in the epilogue (the resnets' conv2)")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
@@ -73,6 +74,7 @@ def main():
         coutp = (cout + 7) // 8 * 8
         out = torch.empty(B, ho, wo, coutp, device=dev, dtype=dt)
         bias = torch.randn(cout, device=dev)
+        resid = torch.randn(B, ho, wo, coutp, device=dev).to(dt) if a.res else None
         gn = 0 if a.nogn else gn
         ss = torch.randn(B, cin, 2, device=dev) if gn else None
         for tile, sk in [(int(t), int(k)) for t in a.tiles.split(",") for k in a.splitk.split(",")]:
@@ -83,7 +85,8 @@ def main():
             prog = K.Program()
             for _ in range(a.iters + 1):
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
-                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws), dt))
+                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws,
+                                      res=resid, ldr=coutp if a.res else None), dt))
             prog.freeze()
             try:
                 ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]

@@ -1,6 +1,6 @@
 // 3x3 stride-1 pad-1 implicit-GEMM convolution, "wide" operating point for gfx950: 32x32x16 MFMA, wave tiles of
-// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file) at ONE wave per SIMD,
-// or 128 x 64 / 64 x 128 at two.  Same replaced reference ops as conv3x3.hip (F.conv2d of diffusers ResnetBlock2D /
+// 128 pixels x 128 channels (4 x 4 fragments = 256 accumulator registers, the whole AGPR file) at ONE wave per SIMD
+// (128 x 64 / 64 x 128 wave tiles at two waves per SIMD spilled with the GroupNorm prologue and were dropped).  Same replaced reference ops as conv3x3.hip (F.conv2d of diffusers ResnetBlock2D /
 // Upsample2D with the preceding F.group_norm + F.silu, torch.cat and nearest-2x folded into the operand staging,
 // bias / residual / next GroupNorm's partial sums in the epilogue); 16-bit dtypes only (the exact-f32 parity mode
 // and planes narrower than 32 stay on conv3x3_halo_kernel).
@@ -451,27 +451,48 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         tx2 ones;
         ones[0] = (T)1.0f; ones[1] = (T)1.0f;
         float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;     // (sum, sum of squares) of the chunk's two channel quads
+        // The residual is requested one (16 x 32 x 128 tile) or two (8 x 32 x 256) tile rows ahead of its use; the staging
+        // registers of the K loop are dead here.  Same-box A/B against fetching each row at its use (W32_RDEPTH=0):
+        // +3..5 % on 128 -> 128 @ 512^2 at depth 1, +2 % on 512 -> 512 @ 128^2 at depth 2, nothing on 256 -> 256
+        // (profiles/r3m_ab_residual_prefetch_and_fused_splitk.log).
+        static_assert(NRND == 1, "");
+#ifndef W32_RDEPTH
+#define W32_RDEPTH (BN == 128 ? 1 : 2)
+#endif
+        constexpr bool RAHEAD = W32_RDEPTH > 0;              // (0: fetch each row at its use -- the A/B baseline)
+        constexpr int RDEPTH = !RAHEAD ? 1 : (FM < W32_RDEPTH ? FM : W32_RDEPTH);
+        chunk_t rr[RES ? RDEPTH : 1][SPX / 4];
+        auto res_load = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (RES && i < FM) {
+                const int oy = ty0 + wm * FM + i;
+                const bool rowok = FULL || oy < p.ho;
+                const T* const rbase = res + (((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0) * p.ldr;      // uniform
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+                for (int k = 0; k < SPX / 4; ++k) {
+                    const bool ok = FULL || (rowok && nok && tx0 + k * 4 + p4 < p.wo);
+                    rr[i % RDEPTH][k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(k * 4 * p.ldr) + r_lane : 0u));
+                }
+            }
+        };
+        if constexpr (RAHEAD) static_for_w<RDEPTH>([&](auto ic) __attribute__((always_inline)) { res_load(ic); });
+        static_for_w<FM>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);                // one tile row at a time (register budget)
             const int oy = ty0 + wm * FM + i;
             const bool rowok = FULL || oy < p.ho;
             const int64_t rowpix = ((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0;     // uniform
             T* const obase = (T*)p.c + rowpix * p.ldc;
-            const T* const rbase = RES ? res + rowpix * p.ldr : nullptr;
+            int blane = lh * 16;                              // (re-derived per row: else the 16 bias quads of the wave stay in 64 registers across the rows)
+            opaque(blane);
 #pragma unroll
             for (int rd = 0; rd < NRND; ++rd) {
-                if constexpr (RES) {                           // (a) residual of the round's pixels, row layout -> stage
-                    chunk_t rr[SPX / 4];
+                if constexpr (RES) {                           // (a) residual of the row's pixels, row layout -> stage
+                    if constexpr (!RAHEAD) res_load(icw<i>{});
 #pragma unroll
-                    for (int k = 0; k < SPX / 4; ++k) {
-                        const int pxr = rd * SPX + k * 4;      // pixel column (without p4) inside the tile row
-                        const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < p.wo);
-                        rr[k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(pxr * p.ldr) + r_lane : 0u));
-                    }
-#pragma unroll
-                    for (int k = 0; k < SPX / 4; ++k) *(chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4))) = rr[k];
+                    for (int k = 0; k < SPX / 4; ++k) *(chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4))) = rr[i % RDEPTH][k];
                     wave_sync();
+                    if constexpr (RAHEAD) res_load(icw<i + RDEPTH>{});      // the registers are free again: row i + RDEPTH
                 }
                 if (NRND == 1 || (l31 / SPX) == rd) {          // (b) the lanes of this round's pixel columns finish their pieces
                     const int px = l31 % SPX;
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             char* const a = prow + (((j * 4 + q) << 4) ^ pswz);
-                            const f32x4 bq = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + lh * 16);
+                            const f32x4 bq = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + blane);
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(p.alpha, acc[i][j][4 * q + r], bq[r]);
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 }
                 wave_sync();                                   // (emulator) the image is free for the next round
             }
-        }
+        });
         // ---- GroupNorm partial sums: lane -> the 4 lanes sharing a chunk (2 shuffles) -> wave (its staging block) ->
         // workgroup -> one slot per (tile, group).  Fixed order: deterministic.
         if (do_stats) {

@@ -9,6 +9,7 @@ executed by one C call (``i2i_run``) or replayed as a hipGraph (``i2i_graph_laun
 Python only allocates tensors and writes op descriptors here; it never computes.
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -106,6 +107,8 @@ class ForwardPlan:
         self._gn_ss_elems = 0
         self._pending_gn = []
         self._keep = []         # tensors referenced by the program that are not owned by the pool
+        self._ckv = None        # merged cross-attention K / V^T of the UNet (see _cross_kv)
+        self.cross_kv_merged = os.environ.get("I2I_CROSS_KV_MERGED", "1") != "0"
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -365,6 +368,33 @@ class ForwardPlan:
         self.pool.put(o)
         return out
 
+    def _cross_kv(self, pk, ctx, tk):
+        """Every cross-attention K and V^T projection of the UNet in TWO launches (diffusers Attention.to_k / to_v of the 16
+        attn2 modules, reference call src/pix2pix_turbo.py:199): they all read the same text states, so their weights are
+        stacked along the output rows (packer.stacked_linear: LoRA re-merge per row block as before) and module i reads its
+        column slice of K_all [ctx_batch*tk][sumC] / its row slice of V^T_all [vb][sumC][ldvt].  32 launch-latency-bound
+        77-row GEMMs (16 to 25 us each) become two.  I2I_CROSS_KV_MERGED=0 keeps one pair per module (A/B)."""
+        if self._ckv is None:
+            names = sorted({k[:k.index(".to_k.")] for k in pk.sd if ".attn2.to_k." in k})
+            widths = [pk.base(n + ".to_k")[0].shape[0] for n in names]
+            offs, tot = {}, 0
+            for n, c in zip(names, widths):
+                offs[n], tot = tot, tot + c
+            cd = self.ua.cross_attention_dim
+            epc = 4 if self.dtype == torch.float32 else 8
+            ldvt = (tk + epc - 1) // epc * epc
+            vb = self.ctx_batch
+            kall = self.linear(pk.stacked_linear([n + ".to_k" for n in names]), ctx, self.ctx_batch * tk, cd, label="attn2.to_k (all modules)")
+            wv = pk.stacked_linear([n + ".to_v" for n in names])
+            assert wv["b"] is None
+            vt = self.pool.get(vb * tot * ldvt, self.dtype)
+            self._add(O.bgemm(wv["w"], ctx, vt, M=tot, N=tk, Kdim=cd, lda=cd, ldb=cd, ldc=ldvt, batch=vb, heads=1,
+                              a_bs=(0, 0), b_bs=((tk * cd if vb > 1 else 0), 0), c_bs=(tot * ldvt, 0)), "attn2.to_v^T (all modules)")
+            self.flops += 2 * vb * tk * tot * cd
+            self._zero_init.append(vt)       # (pad columns of V^T only have to be finite)
+            self._ckv = dict(k=kall, vt=vt, off=offs, tot=tot, ldvt=ldvt)      # never returned to the pool: read until the last block
+        return self._ckv
+
     def attention_block(self, pk, p, xn, x_res, B, T, C, heads, ctx=None, tk=None):
         """attn1 (self) or attn2 (cross, ``ctx`` = text states).  Returns x_res + to_out(attn)."""
         d = C // heads
@@ -377,23 +407,33 @@ class ForwardPlan:
         else:
             cd = self.ua.cross_attention_dim
             q = self.linear(pk.conv(p + ".to_q"), xn, B * T, C, label=p + ".to_q")
-            k = self.linear(pk.conv(p + ".to_k"), ctx, self.ctx_batch * tk, cd, label=p + ".to_k")
-            ldq, ldk, q_bs = C, C, T * C
-            k_bs = tk * C if self.ctx_batch > 1 else 0
-            kv_src, kv_cin, kv_bs = ctx, cd, (tk * cd if self.ctx_batch > 1 else 0)
+            ldq, q_bs = C, T * C
             qk = None
+            merged = self.cross_kv_merged and p.endswith(".attn2")
+            if merged:
+                ck = self._cross_kv(pk, ctx, tk)
+                k, ldk = ck["k"][ck["off"][p]:], ck["tot"]
+                k_bs = tk * ck["tot"] if self.ctx_batch > 1 else 0
+            else:
+                k = self.linear(pk.conv(p + ".to_k"), ctx, self.ctx_batch * tk, cd, label=p + ".to_k")
+                ldk = C
+                k_bs = tk * C if self.ctx_batch > 1 else 0
+            kv_src, kv_cin, kv_bs = ctx, cd, (tk * cd if self.ctx_batch > 1 else 0)
         epc = 4 if self.dtype == torch.float32 else 8
         ldvt = (tk + epc - 1) // epc * epc
-        wv = pk.conv(p + ".to_v")
         vb = B if (ctx is None or self.ctx_batch > 1) else 1
-        vt = self.pool.get(vb * C * ldvt, self.dtype)
-        self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
-                          a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T")
-        self.flops += 2 * vb * tk * C * kv_cin
+        if ctx is not None and merged:
+            vt, vt_stride = ck["vt"][ck["off"][p] * ldvt:], ck["tot"] * ldvt        # rows off .. off + C of every image's V^T_all
+        else:
+            wv = pk.conv(p + ".to_v")
+            vt, vt_stride = self.pool.get(vb * C * ldvt, self.dtype), C * ldvt
+            self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
+                              a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T")
+            self.flops += 2 * vb * tk * C * kv_cin
         o = self.pool.get(B * T * C, self.dtype)
         if self.flash and d == 64:
             self._add(O.attention(q, k, vt, o, batch=B, heads=heads, d=d, tq=T, tk=tk, ldq=ldq, ldk=ldk, ldvt=ldvt, ldo=C,
-                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(C * ldvt if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa")
+                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(vt_stride if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa")
         else:
             ldp = ldvt
             s = self.pool.get(B * heads * T * tk, torch.float32)
@@ -404,16 +444,19 @@ class ForwardPlan:
             self.pool.put(s)
             # V^T pad columns are multiplied by exact zeros of P; keep them finite
             self._add(O.bgemm(pm, vt, o, M=T, N=d, Kdim=ldp, lda=ldp, ldb=ldvt, ldc=C, batch=B, heads=heads,
-                              a_bs=(heads * T * ldp, T * ldp), b_bs=((C * ldvt if vb > 1 else 0), d * ldvt), c_bs=(T * C, d)), p + ".pv")
+                              a_bs=(heads * T * ldp, T * ldp), b_bs=((vt_stride if vb > 1 else 0), d * ldvt), c_bs=(T * C, d)), p + ".pv")
             self.pool.put(pm)
-            self._zero_init.append(vt)
+            if not (ctx is not None and merged):
+                self._zero_init.append(vt)
         self.flops += 4 * B * heads * T * tk * d
         if qk is not None:
             self.pool.put(qk)
         else:
             self.pool.put(q)
-            self.pool.put(k)
-        self.pool.put(vt)
+        if ctx is None or not merged:
+            if qk is None:
+                self.pool.put(k)
+            self.pool.put(vt)
         out = self.linear(pk.conv(p + ".to_out.0"), o, B * T, C, res=x_res, label=p + ".to_out")
         self.pool.put(o)
         return out
