@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         // The residual is requested one (16 x 32 x 128 tile) or two (8 x 32 x 256) tile rows ahead of its use; the staging
         // registers of the K loop are dead here.  Same-box A/B against fetching each row at its use (W32_RDEPTH=0):
         // +3..5 % on 128 -> 128 @ 512^2 at depth 1, +2 % on 512 -> 512 @ 128^2 at depth 2, nothing on 256 -> 256
-        // (profiles/r3m_ab_residual_prefetch_and_fused_splitk.log).
+        // (profiles/r3m_ab_residual_prefetch_fused_splitk_merged_cross_kv.log).
         static_assert(NRND == 1, "");
 #ifndef W32_RDEPTH
 #define W32_RDEPTH (BN == 128 ? 1 : 2)
