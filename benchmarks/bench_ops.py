@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--lib", default=None, help="alternate build of the library (ablation experiments)")
     ap.add_argument("--splitk", default="0", help="comma list of split-K factors to try (LDS-DMA igemm)")
     ap.add_argument("--trace", action="store_true", help="library built with -DI2I_TRACE=1: print the per-segment cycle split of the halo conv")
+    ap.add_argument("--subpix", action="store_true", help="upsampler shapes (ups = 1) in the sub-pixel form the product uses ([4][N][2][2][cin] weights)")
     ap.add_argument("--res", action="store_true", help="add a residual tensor in the epilogue (the resnets' conv2)")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     a = ap.parse_args()
@@ -70,6 +71,9 @@ def main():
         B = a.batch
         x = torch.randn(B, H, W, cin, device=dev).to(dt)
         w = (torch.randn(cout, ks * ks * cin, device=dev) / math.sqrt(ks * ks * cin)).to(dt)
+        sp = 1 if (a.subpix and ups == 1 and ks == 3) else 0
+        if sp:
+            w = (torch.randn(4 * cout, 4 * cin, device=dev) / math.sqrt(4 * cin)).to(dt)
         ho, wo = (H << ups) // stride, (W << ups) // stride
         coutp = (cout + 7) // 8 * 8
         out = torch.empty(B, ho, wo, coutp, device=dev, dtype=dt)
@@ -85,7 +89,7 @@ def main():
             prog = K.Program()
             for _ in range(a.iters + 1):
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
-                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws,
+                                      N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws, subpix=sp,
                                       res=resid, ldr=coutp if a.res else None), dt))
             prog.freeze()
             try:

@@ -83,22 +83,32 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }    
 
 constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
 // bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
-constexpr int w32_plane(int th) { return (((th + 2) * (W32_TW + 2) * 32 + 127) / 128) * 128 + 32; }
+constexpr int w32_plane_px(int halo_px) { return ((halo_px * 32 + 127) / 128) * 128 + 32; }
+constexpr int w32_plane(int th, bool subpix = false) { return w32_plane_px(subpix ? (th + 1) * (W32_TW + 1) : (th + 2) * (W32_TW + 2)); }
 
 // GN: GroupNorm affine + SiLU applied while staging (p.gn_ss != nullptr, p.act == 1); otherwise raw staging.
 // RES: residual tensor added in the epilogue (p.res != nullptr).
-template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES>
+// SUBPIX: the sub-pixel form of "nearest-2x upsample, then 3x3 conv" (diffusers Upsample2D; conv3x3.hip has the same form on
+// its tiles): output pixel (2y+a, 2x+b) only sees a 2x2 neighbourhood of the SOURCE plane, so each output parity (a, b) is a
+// 2x2 convolution of the source with pre-summed tap weights (packer.subpixel_weights, [4][N][2][2][cin]) -- 4/9 of the MFMA
+// work.  A workgroup owns TH x 32 SOURCE positions of one parity: halo (TH+1) x 33 with its origin shifted by the parity,
+// 4 taps per slab, 2-deep weight ring (4 % 2 == 0 keeps the ring slot a compile-time constant), outputs scattered to
+// (2y+a, 2x+b) as full 256-byte lines.  The Upsample2D conv has neither a norm in front nor a residual.
+template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES, bool SUBPIX = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const int xcd_tn) {
-    constexpr int TW = W32_TW, CK = W32_CK, RING = W32_RING, NTAPS = 9;
+    static_assert(!SUBPIX || (!GN && !RES), "");
+    constexpr int KS = SUBPIX ? 2 : 3, NPAR = SUBPIX ? 4 : 1;
+    constexpr int TW = W32_TW, CK = W32_CK, RING = SUBPIX ? 2 : W32_RING, NTAPS = KS * KS;
+    static_assert(NTAPS % RING == 0, "the ring slot of a tap is a compile-time constant");
     constexpr int NW = WM * WN, NT = NW * 64;
-    constexpr int HW2 = TW + 2, HALO = (TH + 2) * HW2;
+    constexpr int HW2 = TW + KS - 1, HALO = (TH + KS - 1) * HW2;
     static_assert(TH % WM == 0 && BN % (32 * WN) == 0, "");
     constexpr int FM = TH / WM, WTN = BN / WN, FN = WTN / 32;
     constexpr int HPT = (HALO * 8 + NT - 1) / NT;      // halo chunks per thread per slab
     constexpr int NPIECE = BN / 8;                     // 1-KiB LDS-DMA pieces per weight slab
     static_assert(NPIECE % NW == 0, "every wave issues the same number of DMA pieces");
     constexpr int BPW = NPIECE / NW;
-    constexpr int PLANE = w32_plane(TH);
+    constexpr int PLANE = w32_plane(TH, SUBPIX);
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit dtypes only");
 
@@ -126,13 +136,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // the SAME BN rows of the weight matrix (512 -> 512: 2.4 MB instead of 4.7 MB against a 4 MB L2; with both channel tiles
     // on one XCD the weight DMA alone cost 30 % of a kernel, profiles/r3g_w32_ablation.log) and the spatial tiles are split
     // into 8 / ntn contiguous runs.  Otherwise every XCD gets one contiguous run of (tile, channel tile) pairs.
-    const int tiles_x = (p.wo + TW - 1) / TW, tiles_y = (p.ho + TH - 1) / TH;
+    const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;       // the plane the tiles walk
+    const int tiles_x = (pl_w + TW - 1) / TW, tiles_y = (pl_h + TH - 1) / TH;
     const int ntn = (p.N + BN - 1) / BN;
     int tn, bid;
     {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         if (xcd_tn) {
-            const int nsp = tiles_x * tiles_y * p.nimg, ng = 8 / ntn, grp = xcd / ntn;
+            const int nsp = tiles_x * tiles_y * p.nimg * NPAR, ng = 8 / ntn, grp = xcd / ntn;
             const int q = nsp / ng, r = nsp % ng;
             if (idx >= q + (grp < r ? 1 : 0)) return;              // (runs differ by one tile: uniform exit of the surplus workgroup)
             tn = xcd % ntn;
@@ -143,6 +154,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             tn = bid % ntn; bid /= ntn;
         }
     }
+    int pa = 0, pb = 0;                                  // output parity (row, column) of this workgroup: fastest tile index
+    if (SUBPIX) { pa = (bid >> 1) & 1; pb = bid & 1; bid >>= 2; }
     const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * TH;
     const int img = bid / tiles_y;
@@ -150,9 +163,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 
     const T* __restrict__ a0 = (const T*)p.a0;
     const T* __restrict__ a1 = (const T*)p.a1;
-    const T* __restrict__ bw = (const T*)p.b;
     const int cin = p.c0 + p.c1;
-    const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
+    const T* __restrict__ bw = (const T*)p.b + (SUBPIX ? (int64_t)(pa * 2 + pb) * p.N * p.ldb : 0);
+    const int hin_up = SUBPIX ? p.hin : (p.up_h ? p.up_h : (p.hin << p.ups)), win_up = SUBPIX ? p.win : (p.up_w ? p.up_w : (p.win << p.ups));
 
     // LDS map.  Halo: FOUR planes, one per k16 step (channels 16*kk .. +15 of the slab), rows of 32 bytes = 2 chunks,
     // chunk h of row r at physical chunk h ^ ((r>>3)&1): a fragment read (32 consecutive rows, lanes 0-31 chunk 0,
@@ -177,9 +190,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         bool pad = true;
         if (hp < HALO) {
             const int hy = hp / HW2, hx = hp - hy * HW2;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;           // coordinates in the (upsampled) input plane
+            const int iy = ty0 + hy + pa - 1, ix = tx0 + hx + pb - 1;      // coordinates in the (upsampled) input plane; SUBPIX: source plane
             if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up) {
-                pix = (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
+                pix = SUBPIX ? (unsigned)(iy * p.win + ix)
+                             : (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
                 pad = false;
             }
         }
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 
     chunk_t xf[2][FM], wf[2][FN];
     auto xread = [&](int tap, int i, int kk) __attribute__((always_inline)) -> chunk_t {
-        const int c = (i + tap / 3) * HW2 + tap % 3;
+        const int c = (i + tap / KS) * HW2 + tap % KS;
         return *(const chunk_t*)(i2i_smem + x_off[c & 15] + (kk * PLANE + c * 32));
     };
     auto wread = [&](int buf, int j, int kk) __attribute__((always_inline)) -> chunk_t {
@@ -307,9 +321,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // covered by the counted wait of P_{t+2}), transformed during step t+3 (q-th chunk of the window beside k16 step q),
     // stored after P_8 -- when every fragment read of the current halo has completed -- in the shadow of the slab's
     // last 16 MFMAs.  ONE extra barrier per slab, no serial hand-over.
-    constexpr int LW = 6;
+    constexpr int LW = SUBPIX ? 2 : 6;
     auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c; return c; };
-    static_assert(HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
+    static_assert(SUBPIX || HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
 
     // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
     // reads of the NEXT k16 step go out beside its first MFMAs (weights first: the i-major MFMA order needs every weight
@@ -355,11 +369,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto step = [&](int slab, auto tapc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
         // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
+        // (SUBPIX: four taps per slab and no transform -- the chunks are fenced and their padding zeroed at the store)
         auto xf_q = [&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
-            if constexpr (tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
+            if constexpr (!SUBPIX && tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
         };
-        auto has_q = [&](int q) constexpr { return tap >= 3 && tap - 3 + q * LW < HPT; };
+        auto has_q = [&](int q) constexpr { return !SUBPIX && tap >= 3 && tap - 3 + q * LW < HPT; };
         kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
         kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
         kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
@@ -367,7 +382,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         W32_TR(1);
         // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
         //    its halo loads and its DMA batch.
-        wait_vmcnt<DMA_OPS + nh(tap - 1)>();
+        //    (two-deep ring: the awaited batch is the youngest operation in flight)
+        wait_vmcnt<RING == 2 ? 0 : DMA_OPS + nh(tap - 1)>();
         W32_TR(2);
         lds_barrier();
         W32_TR(3);
@@ -386,7 +402,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
               [&]() __attribute__((always_inline)) {
                   if constexpr (tap == NTAPS - 1) {
 #pragma unroll
-                      for (int j = 0; j < HPT; ++j) halo_store(j);
+                      for (int j = 0; j < HPT; ++j) {
+                          if constexpr (SUBPIX) { reg_fence(rh[j]); halo_xform(j); }
+                          halo_store(j);
+                      }
                   }
 #pragma unroll
                   for (int q = 0; q < BPW; ++q) {
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // quad).  The residual is loaded in the row layout (full lines), staged through the same image and added in fp32
     // before the one rounding.
     constexpr int SPX = 32, NRND = 1;                    // a whole 32-pixel tile row per staging round
-    static_assert(WTN == 128 && 4 * w32_plane(TH) >= NW * SPX * 256, "");
+    static_assert(WTN == 128 && 4 * PLANE >= NW * SPX * 256, "");
     typedef T tx4 __attribute__((ext_vector_type(4)));
     typedef T tx2 __attribute__((ext_vector_type(2)));
     const T* __restrict__ res = (const T*)p.res;
@@ -447,7 +466,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         const bool nok = FULL || nrb < p.N;
         // byte offsets of this lane's row-layout chunk inside the staging image (pixel k*4 + p4) and of its pieces
         const int rl_off = p4 * 256 + ((c16 ^ p4) << 4);      // + k*1024 + ((k*4) & 12) folded below: (k*4+p4)&15 = (k*4 & 12) | p4
-        const unsigned o_lane = (unsigned)(p4 * p.ldc + nrb), r_lane = RES ? (unsigned)(p4 * p.ldr + nrb) : 0u;
+        constexpr int PXS = SUBPIX ? 2 : 1;               // output pixels per tile pixel along a row (sub-pixel form: every other one)
+        const unsigned o_lane = (unsigned)(PXS * p4 * p.ldc + nrb), r_lane = RES ? (unsigned)(p4 * p.ldr + nrb) : 0u;
         tx2 ones;
         ones[0] = (T)1.0f; ones[1] = (T)1.0f;
         float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;     // (sum, sum of squares) of the chunk's two channel quads
@@ -479,9 +499,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         static_for_w<FM>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);                // one tile row at a time (register budget)
-            const int oy = ty0 + wm * FM + i;
-            const bool rowok = FULL || oy < p.ho;
-            const int64_t rowpix = ((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0;     // uniform
+            const int sy = ty0 + wm * FM + i;                 // row in the plane the tiles walk
+            const bool rowok = FULL || sy < pl_h;
+            const int oy = SUBPIX ? 2 * sy + pa : sy;
+            const int64_t rowpix = ((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + (SUBPIX ? 2 * tx0 + pb : tx0);     // uniform
             T* const obase = (T*)p.c + rowpix * p.ldc;
             int blane = lh * 16;                              // (re-derived per row: else the 16 bias quads of the wave stay in 64 registers across the rows)
             opaque(blane);
@@ -528,8 +549,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 for (int k = 0; k < SPX / 4; ++k) {
                     const int pxr = rd * SPX + k * 4;
                     chunk_t c = *(const chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4)));
-                    const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < p.wo);
-                    if (ok && !W32_ABL(1)) *(chunk_t*)(orow + (unsigned)(pxr * p.ldc)) = c;
+                    const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < pl_w);
+                    if (ok && !W32_ABL(1)) *(chunk_t*)(orow + (unsigned)(PXS * pxr * p.ldc)) = c;
                     if (!FULL && !ok) c = zero_chunk<T>();
                     tx2 d0, d1, d2, d3;
                     d0[0] = c[0]; d0[1] = c[1]; d1[0] = c[2]; d1[1] = c[3]; d2[0] = c[4]; d2[1] = c[5]; d3[0] = c[6]; d3[1] = c[7];
@@ -565,8 +586,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                     const float* sw = (const float*)(i2i_smem + (wmm * WN + wnn) * (SPX * 256));
                     for (int q = q0; q < q0 + nq; ++q) { S += sw[q * 2]; Q += sw[q * 2 + 1]; }
                 }
-                const int tile_in_img = (ty0 / TH) * tiles_x + tx0 / TW;
-                float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y) + tile_in_img) * groups + g) * 2;
+                const int tile_in_img = ((ty0 / TH) * tiles_x + tx0 / TW) * NPAR + pa * 2 + pb;      // (one slot per tile and parity)
+                float* out = p.gn_part + (((int64_t)img * (tiles_x * tiles_y * NPAR) + tile_in_img) * groups + g) * 2;
                 out[0] = S;
                 out[1] = Q;
             }
@@ -588,13 +609,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 
 template <typename T, int TH, int BN, int WM, int WN>
 int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
-    const int nsp = ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + TH - 1) / TH) * p.nimg, ntn = (p.N + BN - 1) / BN;
+    const int pl_h = p.subpix ? p.hin : p.ho, pl_w = p.subpix ? p.win : p.wo;
+    const int nsp = ((pl_w + W32_TW - 1) / W32_TW) * ((pl_h + TH - 1) / TH) * p.nimg * (p.subpix ? 4 : 1), ntn = (p.N + BN - 1) / BN;
     const bool xcd_off = getenv("I2I_W32_XCDTN") && atoi(getenv("I2I_W32_XCDTN")) == 0;      // A/B / test hook, read per launch
     const int xcd_tn = (8 % ntn == 0 && !xcd_off) ? 1 : 0;
     const unsigned tiles = xcd_tn ? 8u * (unsigned)((nsp + 8 / ntn - 1) / (8 / ntn)) : (unsigned)(nsp * ntn);
     const bool gn = p.gn_ss != nullptr;
     const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
     const dim3 g(tiles), b(WM * WN * 64);
+    if (p.subpix) {
+        const size_t smem_sp = 4 * w32_plane(TH, true) + 1024 + 2 * BN * 128 + BN * 4;        // 2-deep weight ring
+        hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true>), g, b, smem_sp, s, p, xcd_tn);
+        return i2i::check_launch("conv3x3_w32<SUBPIX>");
+    }
     if (gn && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, xcd_tn);
     else if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p, xcd_tn);
     else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p, xcd_tn);
@@ -631,15 +658,19 @@ int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
 namespace i2i {
 // Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
 // counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
-// together with SiLU.  Not the sub-pixel form.
+// together with SiLU; the sub-pixel upsampler form on source planes of at least 8 x 32.
 bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
-    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.subpix || p.out_f32 || p.act_out) return false;
+    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.out_f32 || p.act_out) return false;
     if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
-    if (p.wo < W32_TW || p.ho < 8 || p.N < 128 || p.N % 8) return false;
+    if (p.N < 128 || p.N % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
+    if (p.subpix) {      // sub-pixel upsampler: tiles walk the SOURCE plane, weights [4 parities][N][4*cin]; no norm, no residual
+        if (p.ups != 1 || p.up_h || p.up_w || p.gn_ss || p.act || p.res || p.ldb != 4 * (p.c0 + p.c1)) return false;
+        return p.win >= W32_TW && p.hin >= 8 && p.ho == 2 * p.hin && p.wo == 2 * p.win;
+    }
+    if (p.wo < W32_TW || p.ho < 8) return false;
     if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
     if ((p.up_h || p.up_w) && p.ups != 1) return false;
-    if (p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     if (p.gn_ss && p.act != 1) return false;
     if (!p.gn_ss && p.act) return false;
     return true;
@@ -651,7 +682,8 @@ bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype) {
     if (!conv3x3_w32_eligible(p, dtype) || p.N % 128) return false;
     int th, bn, wtn;
     w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
-    const long tiles = (long)p.nimg * ((p.ho + th - 1) / th) * ((p.wo + W32_TW - 1) / W32_TW) * ((p.N + bn - 1) / bn);
+    const int pl_h = p.subpix ? p.hin : p.ho, pl_w = p.subpix ? p.win : p.wo;
+    const long tiles = (long)p.nimg * ((pl_h + th - 1) / th) * ((pl_w + W32_TW - 1) / W32_TW) * ((p.N + bn - 1) / bn) * (p.subpix ? 4 : 1);
     return tiles >= 224;
 }
 int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
@@ -660,7 +692,8 @@ int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     int th, bn, wtn;
     w32_cfg_geometry(w32_cfg(p), &th, &bn, &wtn);
     if (cpg % 4 || wtn % cpg || bn % cpg) return 0;        // the epilogue sums channel quads
-    return ((p.wo + W32_TW - 1) / W32_TW) * ((p.ho + th - 1) / th);
+    const int pl_h = p.subpix ? p.hin : p.ho, pl_w = p.subpix ? p.win : p.wo;
+    return ((pl_w + W32_TW - 1) / W32_TW) * ((pl_h + th - 1) / th) * (p.subpix ? 4 : 1);      // one slot per tile (and parity)
 }
 int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     switch (dtype) {

@@ -346,7 +346,7 @@ extern "C" const char* i2i_igemm_route(const i2i_igemm_params* pp, int dtype) {
     i2i_igemm_params p = *pp;
     if (p.zcount < 1) p.zcount = 1;
     if (p.zh_count < 1) p.zh_count = 1;
-    if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return "conv3x3_w32_kernel";
+    if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return p.subpix ? "conv3x3_w32_kernel<SUBPIX>" : "conv3x3_w32_kernel";
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return p.subpix ? "conv3x3_halo_kernel<SUBPIX>" : "conv3x3_halo_kernel";
     if ((p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) && i2i::igemm_dma_eligible(p, dtype)) return "igemm_dma_kernel";

@@ -399,6 +399,23 @@ def test_w32_conv_three_slabs_one_slab_and_route(emu_lib):
     assert emu_lib.igemm_route(p3, K.F32) == "conv3x3_halo_kernel"          # exact-f32 parity mode stays on the halo kernel
 
 
+@pytest.mark.parametrize("cfg", W32_TILES)
+def test_w32_subpixel_upsample_conv(emu_lib, cfg):
+    """Sub-pixel Upsample2D form on the wide tiles: four parity workgroups per source tile (halo origin shifted by the parity),
+    four taps per slab on a two-deep weight ring, outputs scattered to (2y+a, 2x+b); ragged source tiles in both directions,
+    two slabs / one slab, ragged channel tile, GroupNorm partial sums with one slot per tile and parity; the route query."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=256, h=20, w=40, ups=1, subpix=True, tile=cfg)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=136, h=9, w=33, ups=1, subpix=True, tile=cfg, seed=4)
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=256, h=12, w=40, groups=32, subpix=True, tile=cfg, res=False)
+    x = torch.zeros(8, 64, 64, 256, dtype=torch.bfloat16)
+    w = torch.zeros(4 * 256, 4 * 256, dtype=torch.bfloat16)
+    out = torch.zeros(8, 128, 128, 256, dtype=torch.bfloat16)
+    _, p = O.conv(x, w, out, nimg=8, hin=64, win=64, ho=128, wo=128, ks=3, pad=1, ups=1, N=256, subpix=1)
+    assert emu_lib.igemm_route(p, K.BF16) == "conv3x3_w32_kernel<SUBPIX>"
+    _, p1 = O.conv(x[:1, :16, :16], w, out[:1, :32, :32], nimg=1, hin=16, win=16, ho=32, wo=32, ks=3, pad=1, ups=1, N=256, subpix=1)
+    assert emu_lib.igemm_route(p1, K.BF16) == "conv3x3_halo_kernel<SUBPIX>"      # source plane narrower than a 32-wide tile
+
+
 @pytest.mark.parametrize("xcdtn", [None, "0"])
 @pytest.mark.parametrize("cfg", [41, 42])
 def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, xcdtn, monkeypatch):

@@ -148,6 +148,17 @@ def test_dma_igemm_epilogue_groupnorm_partials(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_subpixel_upsample_conv(gpu_lib, cfg):
+    """Sub-pixel Upsample2D form on the wide tiles (conv3x3_w32.hip SUBPIX): the decoder's two big upsamplers at their real
+    shapes, ragged source tiles, GroupNorm partial sums per tile and parity."""
+    oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=36, w=52, ups=1, subpix=True, tile=cfg)           # ragged both ways
+    oc.check_conv(gpu_lib, "cuda", torch.float16, n=4, cin=256, cout=256, h=64, w=64, ups=1, subpix=True, tile=cfg)
+    oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=512, cout=512, h=64, w=64, ups=1, subpix=True, tile=cfg)           # 8 slabs
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=40, w=52, groups=32, subpix=True, tile=cfg, res=False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_subpixel_upsampler_groupnorm_partials(gpu_lib, dtype):
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=128, cout=128, h=40, w=52, groups=32, subpix=True)        # 8-row tiles, ragged
