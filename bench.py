@@ -93,6 +93,9 @@ def kernel_roofline(plan, dtype_name, reps=2):
     f3 = sum(fam[k][1] for k in halo)
     n3 = sum(fam[k][2] for k in halo)
     achieved = f3 / (t3 * 1e-3) / 1e12
+    # the sub-pixel upsampler form executes 4/9 of the algorithmic FLOPs of upsample + 3x3 conv: report the matrix-pipe rate too
+    f3x = sum(fam[k][1] * (4.0 / 9.0 if "<SUBPIX>" in k else 1.0) for k in halo)
+    executed = f3x / (t3 * 1e-3) / 1e12
     peak = PEAK_TF[dtype_name]
     traffic, traffic_src = None, None
     if os.path.exists(TRAFFIC_JSON):
@@ -101,11 +104,15 @@ def kernel_roofline(plan, dtype_name, reps=2):
         # only for the build and workload the counters were collected on; anything else reports null rather than a stale number
         if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name and tj.get("size") == plan.H and tj.get("source_hash") == source_hash():
             traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("collected")
-    roof = {"bound": "mfma", "kernel": "conv3x3_w32_kernel + conv3x3_halo_kernel (every 3x3 stride-1 conv of the step: wide-tile 32x32x16-MFMA kernel, "
-                                       "halo kernel for small planes and the sub-pixel upsampler form)",
+    roof = {"bound": "mfma", "kernel": "conv3x3_w32_kernel[<SUBPIX>] + conv3x3_halo_kernel[<SUBPIX>] (every 3x3 stride-1 conv of the step: wide-tile 32x32x16-MFMA "
+                                       "kernel incl. the sub-pixel upsampler form, halo kernel for small planes / odd channel counts)",
             "per_kernel": {k: {"launches": fam[k][2], "avg_launch_ms": round(fam[k][0] / fam[k][2], 4),
                                "tflops": round(fam[k][1] / (fam[k][0] * 1e-3) / 1e12, 1)} for k in halo},
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "executed": round(executed, 2), "frac_executed": round(executed / peak, 4),
+            "executed_note": "achieved counts the ALGORITHMIC FLOPs of the reference ops (9 taps for upsample + conv); executed counts what the "
+                             "matrix pipe really does (<SUBPIX> launches: 4/9)",
+            "traffic": traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, MI355X_MICROARCH.md HBM section)",
             "traffic_source": traffic_src,
             "launches": n3, "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),

@@ -89,7 +89,8 @@ typedef struct {
     int32_t out_f32;           /* 1: store fp32 regardless of dtype (attention scores) */
     int32_t tile;              /* 0 = auto; else forces a kernel / tile config id (tests / tuning):
                                   1-5 register-staged igemm, 10-19 / 30-39 halo conv3x3, 20-25 LDS-DMA igemm,
-                                  40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto) */
+                                  40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto; with `subpix` its
+                                  sub-pixel upsampler form) */
     int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
     void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */
     float* gn_part;            /* optional: GroupNorm partial sums of the OUTPUT tensor (as stored), written by the
@@ -247,8 +248,8 @@ int i2i_igemm(const i2i_igemm_params* p, int dtype, void* stream);
 /* Number of partial-sum slots per image this op would write through gn_part (its spatial tile count), or 0 if
  * the kernel that will run it cannot produce GroupNorm partials (planner query; launches nothing). */
 int i2i_igemm_gn_parts(const i2i_igemm_params* p, int dtype, int groups);
-/* Name of the kernel family i2i_igemm() routes this op to ("conv3x3_w32_kernel", "conv3x3_halo_kernel",
- * "conv3x3_halo_kernel<SUBPIX>", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
+/* Name of the kernel family i2i_igemm() routes this op to ("conv3x3_w32_kernel", "conv3x3_w32_kernel<SUBPIX>",
+ * "conv3x3_halo_kernel", "conv3x3_halo_kernel<SUBPIX>", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
  * timings by it; the planner does not have to mirror the routing rules).  Launches nothing; never NULL. */
 const char* i2i_igemm_route(const i2i_igemm_params* p, int dtype);
 int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);
