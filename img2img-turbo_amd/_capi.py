@@ -30,7 +30,8 @@ class IgemmParams(C.Structure):
                 ("res", vp), ("ldr", i32), ("r_bs_b", i64), ("r_bs_h", i64),
                 ("c", vp), ("ldc", i32), ("c_bs_b", i64), ("c_bs_h", i64),
                 ("zcount", i32), ("zh_count", i32), ("geglu", i32), ("out_f32", i32), ("tile", i32),
-                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32), ("act_out", i32), ("up_h", i32), ("up_w", i32)]
+                ("splitk", i32), ("ws", vp), ("gn_part", vp), ("gn_part_groups", i32), ("subpix", i32), ("act_out", i32), ("up_h", i32), ("up_w", i32),
+                ("k2_a", vp), ("k2_b", vp), ("k2_c", i32), ("k2_lda", i32), ("k2_ldb", i32)]
 
 
 class GnStatsParams(C.Structure):
@@ -178,7 +179,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 4:
+        if L.i2i_abi_version() != 5:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

@@ -439,6 +439,71 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
 
     lds_barrier();                                       // every wave is done with the halo planes / the ring: the staging blocks reuse them
+
+    // ---- second contraction (p.k2_a; sub-pixel form only): acc += k2_a[pixel][0..k2_c) . k2_b[n][0..k2_c)^T with the pixels taken at
+    // the OUTPUT positions of this parity -- the decoder's `sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) folded
+    // into the Upsample2D conv that produces `sample`: the 1x1 skip convolution costs 64-channel slabs of one tap here instead of a
+    // read-modify-write pass over the whole stream.  Per slab: weights by LDS-DMA into ring slot 0, the tile's TH x 32 pixels into
+    // the halo planes at (row, column) = tap (0, 0) positions, four k16 steps; the next slab's loads fly under them.
+    if constexpr (SUBPIX) {
+        if (p.k2_a) {
+            int t2 = tid;
+            opaque(t2);                                   // nothing below shares a value with the staging constants of the main loop
+            const int kc2 = t2 & 7, ln2 = t2 & 63;
+            const char* k2img = (const char*)p.k2_a + (int64_t)img * p.ho * p.wo * p.k2_lda * (int)sizeof(T);
+            unsigned k2pix[HPT], k2ok = 0;
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) {
+                const int hp = (t2 >> 3) + j * (NT / 8);
+                const int hy = hp / HW2, hx = hp - hy * HW2;
+                const bool ok = hy < TH && hx < TW && ty0 + hy < p.hin && tx0 + hx < p.win;
+                k2pix[j] = ok ? (unsigned)((2 * (ty0 + hy) + pa) * p.wo + 2 * (tx0 + hx) + pb) * (unsigned)p.k2_lda * (unsigned)sizeof(T) + (unsigned)kc2 * 16u : 0u;
+                k2ok |= (ok ? 1u : 0u) << j;
+            }
+            unsigned k2w[BPW];
+#pragma unroll
+            for (int q = 0; q < BPW; ++q) {
+                const int row = (wave + q * NW) * 8 + (ln2 >> 3);
+                int n = n0 + row;
+                n = n < p.N ? n : p.N - 1;
+                k2w[q] = (unsigned)(n * p.k2_ldb + (((ln2 & 7) ^ swz3(row)) * 8)) * (unsigned)sizeof(T);
+            }
+            const int nsl2 = p.k2_c / CK;
+            // slab sl+1's pixels (registers) and weights (the other ring slot) are requested before slab sl's MFMAs
+            chunk_t rk[HPT];
+            auto k2_issue = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < BPW; ++q)
+                    glds16_sv((const char*)((const T*)p.k2_b + sl * CK), k2w[q], Bs + (sl & 1) * BN * 128 + (wave + q * NW) * 1024);
+#pragma unroll
+                for (int j = 0; j < HPT; ++j) rk[j] = *(const chunk_t*)(k2img + (size_t)(k2pix[j] + (unsigned)(sl * CK * (int)sizeof(T))));
+            };
+            k2_issue(0);
+            for (int sl = 0; sl < nsl2; ++sl) {
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int j = 0; j < HPT; ++j) {
+                    rh[j] = ((k2ok >> j) & 1u) ? rk[j] : zero_chunk<T>();
+                    halo_store(j);
+                }
+                lds_barrier();
+                if (sl + 1 < nsl2) k2_issue(sl + 1);
+                const int wsl = (sl & 1) * BN * 128;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[0][j] = *(const chunk_t*)(i2i_smem + (w_off ^ (kk << 5)) + wsl + j * 4096);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, kk);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i][j] = mma32(wf[0][j], xf[0][i], acc[i][j]);
+                }
+                lds_barrier();                            // the planes / the slot are free for the next slab (or the epilogue's staging)
+            }
+        }
+    }
     // ---- epilogue of one tile.  acc[i][j][r]: pixel (tile row wm*FM+i, column l31), channels j*32 + 8*(r>>2) + 4*lh + (r&3):
     // per register quad a lane owns 4 consecutive channels = an 8-byte piece of the pixel's 256-byte row (the wave's 128
     // channels).  The pieces go straight into a wave-private LDS image of SPX pixel rows (16-byte chunk c of pixel px at
@@ -664,6 +729,8 @@ bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.out_f32 || p.act_out) return false;
     if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
     if (p.N < 128 || p.N % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
+    if (p.k2_a && (!p.subpix || !p.k2_b || p.k2_c < W32_CK || p.k2_c % W32_CK || p.k2_lda % 8 || p.k2_ldb % 8 || p.k2_lda < p.k2_c || p.k2_ldb < p.k2_c ||
+                   (((uintptr_t)p.k2_a | (uintptr_t)p.k2_b) & 15))) return false;
     if (p.subpix) {      // sub-pixel upsampler: tiles walk the SOURCE plane, weights [4 parities][N][4*cin]; no norm, no residual
         if (p.ups != 1 || p.up_h || p.up_w || p.gn_ss || p.act || p.res || p.ldb != 4 * (p.c0 + p.c1)) return false;
         return p.win >= W32_TW && p.hin >= 8 && p.ho == 2 * p.hin && p.wo == 2 * p.win;

@@ -24,7 +24,7 @@ def _keep(p, *tensors):
 
 def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=None, c0=None, c1=0,
          lda0=None, lda1=None, N=None, ldb=None, gn_ss=None, act=0, bias=None, bias_mode=None, alpha=1.0,
-         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None, act_out=0):
+         res=None, ldr=None, ldc=None, geglu=0, out_f32=0, tile=0, splitk=0, ws=None, subpix=0, up_size=None, act_out=0, k2=None):
     """Implicit-GEMM conv / linear over NHWC sources.  ``w`` is packed [N][ks*ks*(c0+c1)]."""
     p = K.IgemmParams()
     c0 = x0.shape[-1] if c0 is None else c0
@@ -52,7 +52,10 @@ def conv(x0, w, out, *, nimg, hin, win, ho, wo, ks, stride=1, pad=0, ups=0, x1=N
     p.splitk, p.ws, p.subpix = splitk, ptr(ws), subpix
     p.up_h, p.up_w = up_size if up_size else (0, 0)
     p.act_out = act_out
-    return K.OP_IGEMM, _keep(p, x0, x1, w, out, gn_ss, bias, res, ws)
+    if k2 is not None:      # (tensor [nimg][ho][wo][ld], weights [N][ldb], channels): second contraction, see i2i_igemm_params.k2_a
+        k2a, k2b, k2c = k2
+        p.k2_a, p.k2_b, p.k2_c, p.k2_lda, p.k2_ldb = ptr(k2a), ptr(k2b), k2c, k2a.shape[-1], k2b.shape[-1]
+    return K.OP_IGEMM, _keep(p, x0, x1, w, out, gn_ss, bias, res, ws, *(k2[:2] if k2 is not None else ()))
 
 
 def bgemm(a, b, out, *, M, N, Kdim, lda, ldb, ldc, batch, heads, a_bs, b_bs, c_bs, alpha=1.0, out_f32=0,

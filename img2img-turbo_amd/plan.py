@@ -109,6 +109,7 @@ class ForwardPlan:
         self._keep = []         # tensors referenced by the program that are not owned by the pool
         self._ckv = None        # merged cross-attention K / V^T of the UNet (see _cross_kv)
         self.cross_kv_merged = os.environ.get("I2I_CROSS_KV_MERGED", "1") != "0"
+        self.fuse_skip = os.environ.get("I2I_FUSE_SKIP", "1") != "0"       # decoder skip convs folded into the upsamplers (A/B hook)
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -205,20 +206,22 @@ class ForwardPlan:
             return 0, None
         return sk, self.pool.get(sk * M * N, torch.float32)
 
-    def upsample_conv(self, pk, name, x: Act, label, size=None) -> Act:
+    def upsample_conv(self, pk, name, x: Act, label, size=None, k2=None) -> Act:
         """Upsample2D: nearest-2x + 3x3 conv.  Sub-pixel form (4/9 of the MACs, csrc/conv3x3.hip SUBPIX) whenever the
         halo kernel takes it -- slab-aligned channels, source plane of at least one 8x16 tile; else the index-map gather."""
         bk = 32 if self.dtype == torch.float32 else 64
         if size is not None and tuple(size) == (2 * x.h, 2 * x.w):
             size = None
         if size is None and self.subpix and x.c % bk == 0 and x.h >= 8 and x.w >= 16:
-            return self.conv(pk.conv_subpixel(name), x, ups=1, label=label)
+            return self.conv(pk.conv_subpixel(name), x, ups=1, label=label, k2=k2)
         return self.conv(pk.conv(name), x, ups=1, up_size=size, label=label)   # explicit size: F.interpolate(size=...)
 
     def conv(self, pw, x: Act, *, ks=None, stride=1, pad=None, ups=0, up_size=None, asym=False, x1: Optional[Act] = None, gn=False, act=0,
              res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
-             label="") -> Act:
-        """One implicit-GEMM launch.  ``gn``: apply the pending GroupNorm scale/shift (+act) to the A operand."""
+             label="", k2=None) -> Act:
+        """One implicit-GEMM launch.  ``gn``: apply the pending GroupNorm scale/shift (+act) to the A operand.
+        ``k2`` = (Act at output resolution, packed 1x1 weights, label): a second contraction folded into this launch when the
+        kernel it routes to takes one (i2i_igemm_params.k2_a); the returned Act then has ``k2_fused`` set."""
         ks = ks or pw["ks"]
         pad = (ks // 2 if not asym else 0) if pad is None else pad
         hin, win = x.h, x.w
@@ -276,6 +279,17 @@ class ForwardPlan:
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
         fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
         kname = self.lib.igemm_route(op[1], self.dt)     # which kernel the C dispatcher picks (reporting only)
+        out.k2_fused = False
+        if k2 is not None and kname == "conv3x3_w32_kernel<SUBPIX>":
+            k2x, k2w, k2label = k2
+            bk2 = 64
+            if (k2x.n, k2x.h, k2x.w) == (x.n, ho, wo) and k2x.c % bk2 == 0 and k2w["n"] == pw["n"] and k2w["b"] is None and k2w["w"].shape[1] == k2x.c:
+                p_ = op[1]
+                p_.k2_a, p_.k2_b, p_.k2_c, p_.k2_lda, p_.k2_ldb = k2x.t.data_ptr(), k2w["w"].data_ptr(), k2x.c, k2x.c, k2w["w"].shape[1]
+                p_._keep = tuple(p_._keep) + (k2x.t, k2w["w"])
+                fl += 2 * x.n * ho * wo * pw["n"] * k2x.c
+                label = label + " + " + k2label
+                out.k2_fused = True
         if fused and kname == "igemm_kernel":
             kname = "igemm_kernel (register-staged, GN prologue)"
         if halo:
@@ -586,18 +600,24 @@ class ForwardPlan:
         self.free(m)
         h = self.resnet(pk, "decoder.mid_block.resnets.1", m2, rboc[0], g, eps)
         self.free(m2)
+        skip_done = False      # the skip conv of this block already rode in the upsampler that produced h
         for i, c in enumerate(rboc):
             sk = skips[::-1][i]
             # sample = sample + skip_conv_i(skip * gamma)   (src/model.py:41-43), in place
             # (gamma is folded into the skip-conv weights by the device-side merge: Packer.conv(gamma=True))
-            self.conv(pk.conv(f"decoder.skip_conv_{i + 1}", gamma=True), sk, ks=1, res=h, out=h, label=f"decoder.skip_conv_{i + 1}")
+            if not skip_done:
+                self.conv(pk.conv(f"decoder.skip_conv_{i + 1}", gamma=True), sk, ks=1, res=h, out=h, label=f"decoder.skip_conv_{i + 1}")
             self.free(sk)
             for j in range(a.layers_per_block + 1):
                 h2 = self.resnet(pk, f"decoder.up_blocks.{i}.resnets.{j}", h, c, g, eps)
                 self.free(h)
                 h = h2
             if i < len(rboc) - 1:
-                h2 = self.upsample_conv(pk, f"decoder.up_blocks.{i}.upsamplers.0.conv", h, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+                # the NEXT block's `sample + skip_conv(skip * gamma)` as a second contraction of this upsampler (when the wide-tile
+                # sub-pixel kernel takes the launch): the 1x1 skip conv was an HBM-bound read-modify-write of the whole stream
+                k2 = (skips[::-1][i + 1], pk.conv(f"decoder.skip_conv_{i + 2}", gamma=True), f"decoder.skip_conv_{i + 2}") if self.fuse_skip else None
+                h2 = self.upsample_conv(pk, f"decoder.up_blocks.{i}.upsamplers.0.conv", h, f"decoder.up_blocks.{i}.upsamplers.0.conv", k2=k2)
+                skip_done = bool(getattr(h2, "k2_fused", False))
                 self.free(h)
                 h = h2
         self.gn_stats(pk, "decoder.conv_norm_out", h, g, eps)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 4
+#define I2I_ABI_VERSION 5
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -105,6 +105,14 @@ typedef struct {
     int32_t up_h, up_w;        /* ups = 1 only: explicit size of the nearest-upsampled plane (F.interpolate(size=...), the
                                   UNet's forward_upsample_size path for latent sizes that are not multiples of 8);
                                   0,0 = (2*hin, 2*win).  Source index = min(floor(i * in/up), in-1) as ATen computes it */
+    /* Optional SECOND contraction accumulated into the same output before the epilogue:
+     *     out += k2_a[m][0..k2_c) . k2_b[n][0..k2_c)^T,
+     * a 1x1 convolution over another NHWC tensor at OUTPUT resolution ([nimg][ho][wo][k2_lda], same dtype; k2_b is [N][k2_ldb]).
+     * It is the decoder's `sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) folded into the Upsample2D conv
+     * that produces `sample`: no read-modify-write pass over the stream.  k2_c a multiple of 64; taken by the sub-pixel
+     * wide-tile conv only (i2i_igemm_route() == "conv3x3_w32_kernel<SUBPIX>"), anything else returns I2I_ERR_UNSUPPORTED. */
+    const void* k2_a; const void* k2_b;
+    int32_t k2_c, k2_lda, k2_ldb;
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.

@@ -60,7 +60,9 @@ def gn_scale_shift(x, groups, gamma, beta, eps):
 
 
 def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, stride=1, pad=1, ups=0,
-               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4, splitk=0, subpix=False):
+               cin2=0, gn=False, act=0, bias=True, res=False, alpha=1.0, asym_pad=False, tile=0, seed=0, groups=4, splitk=0, subpix=False, k2c=0):
+    """k2c: channels of a second NHWC tensor at output resolution whose 1x1 convolution is accumulated into the same output
+    (i2i_igemm_params.k2_a: the decoder's skip conv folded into the upsampler)."""
     g = torch.Generator().manual_seed(seed)
     ct = cin + cin2
     x = torch.randn(n, ct, h, w, generator=g)
@@ -92,6 +94,12 @@ def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, st
     if res:
         r = torch.randn(n, cout, ho, wo, generator=g)
         ref = ref + r.to(dtype).float()
+    k2 = None
+    if k2c:
+        sk = torch.randn(n, k2c, ho, wo, generator=g)
+        w2 = torch.randn(cout, k2c, generator=g) / math.sqrt(k2c)
+        ref = ref + alpha * F.conv2d(sk.to(dtype).float(), w2.to(dtype).float()[:, :, None, None])
+        k2 = (nhwc(sk, dtype).to(device), w2.to(dtype).contiguous().to(device), k2c)
     # device tensors
     x0 = nhwc(x[:, :cin], dtype).to(device)
     x1 = nhwc(x[:, cin:], dtype).to(device) if cin2 else None
@@ -121,7 +129,7 @@ def check_conv(lib, device, dtype, *, n=2, cin=16, cout=32, h=10, w=12, ks=3, st
     wsd = torch.full((splitk * n * ho * wo * cout,), float("nan"), device=device) if splitk > 1 else None   # keep alive
     opcode, p = O.conv(x0, wp, out, nimg=n, hin=h, win=w, ho=ho, wo=wo, ks=ks, stride=stride, pad=kpad, ups=ups,
                        x1=x1, c0=c0p, c1=c1p, N=cout, gn_ss=ssd, act=act, bias=bd, alpha=alpha, res=rd, tile=tile,
-                       splitk=splitk, ws=wsd, subpix=1 if subpix else 0)
+                       splitk=splitk, ws=wsd, subpix=1 if subpix else 0, k2=k2)
     run_op(lib, opcode, p, dtype, device)
     got = out.cpu().float()[..., :cout].permute(0, 3, 1, 2)
     assert torch.isfinite(got).all(), "non-finite output"

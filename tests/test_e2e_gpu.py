@@ -11,6 +11,8 @@ A dropped skip connection, a missing LoRA branch or a zeroed conv moves max-abs 
 The oracle is per-image independent (per-sample norms and attention), so the BASELINE-scale tests run the GPU at the full
 benchmarked batch and the CPU oracle on a SUBSET of the images (first and last), keeping the CPU time of the suite in minutes.
 """
+import math
+
 import pytest
 import torch
 
@@ -47,6 +49,7 @@ def check(name, out, ref, dtype):
     print(f"[parity] {name}: max-abs {d.max().item():.3e} mean-abs {d.mean().item():.3e} psnr {psnr:.1f} dB")
     assert d.max().item() < TOL[dtype], (name, d.max().item())
     assert psnr > PSNR_MIN[dtype], (name, psnr)
+    return math.sqrt(mse)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -189,6 +192,29 @@ def test_cfg2_pix2pix_bf16_bs8_512(gpu_lib):
     print(f"[parity] fp32 route agreement bs=8 vs bs=1: {d:.3e}")
     assert d < 2e-4, d
     _free(model)
+
+
+def test_decoder_skip_convs_folded_into_the_upsamplers(gpu_lib, monkeypatch):
+    """`sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) of decoder blocks 1..3 rides in the Upsample2D conv
+    that produces `sample` (second contraction of conv3x3_w32_kernel<SUBPIX>, i2i_igemm_params.k2_a).  The folded program has
+    three launches fewer, stays inside the bf16 gate against the oracle at r = gamma = 0.6 (skip weights re-merged on the
+    device), and sits as close to the oracle as the program with separate skip convs (one rounding fewer)."""
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 9, sketch=True)
+    x, cap, eps, nm = make_inputs("sketch", 8, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=9)
+    ref = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.6, noise_map=nm[:1])
+    errs, nops = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("I2I_FUSE_SKIP", flag)
+        model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
+        out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda(), deterministic=False, r=0.6, noise_map=nm.cuda())
+        errs[flag] = check(f"decoder skip convs folded={flag} bf16 bs=8 r=0.6 (image 0)", out[:1], ref, torch.bfloat16)
+        plan = next(iter(model._plans.values()))
+        nops[flag] = len(plan.prog.ops)
+        if flag == "1":
+            assert sum("skip_conv" in l and "upsamplers" in l for l in plan.prog.labels) == 3, [l for l in plan.prog.labels if "skip_conv" in l]
+        _free(model)
+    assert nops["0"] - nops["1"] == 3, nops
+    assert errs["1"] <= 1.1 * errs["0"], errs            # RMS error against the oracle
 
 
 @pytest.mark.parametrize("direction", ["a2b", "b2a"])

@@ -407,6 +407,10 @@ def test_w32_subpixel_upsample_conv(emu_lib, cfg):
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=256, h=20, w=40, ups=1, subpix=True, tile=cfg)
     oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=136, h=9, w=33, ups=1, subpix=True, tile=cfg, seed=4)
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=256, h=12, w=40, groups=32, subpix=True, tile=cfg, res=False)
+    # the decoder's skip conv folded in as a second contraction (k2_a): 2 slabs and 1 slab of skip channels, ragged tiles, alpha
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=20, w=40, ups=1, subpix=True, tile=cfg, k2c=128, seed=7)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=136, h=9, w=33, ups=1, subpix=True, tile=cfg, k2c=64, alpha=0.5, seed=8)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=128, h=8, w=32, ups=1, subpix=True, tile=cfg, k2c=192, seed=9)     # 3 slabs: ring slot reuse
     x = torch.zeros(8, 64, 64, 256, dtype=torch.bfloat16)
     w = torch.zeros(4 * 256, 4 * 256, dtype=torch.bfloat16)
     out = torch.zeros(8, 128, 128, 256, dtype=torch.bfloat16)
@@ -414,6 +418,10 @@ def test_w32_subpixel_upsample_conv(emu_lib, cfg):
     assert emu_lib.igemm_route(p, K.BF16) == "conv3x3_w32_kernel<SUBPIX>"
     _, p1 = O.conv(x[:1, :16, :16], w, out[:1, :32, :32], nimg=1, hin=16, win=16, ho=32, wo=32, ks=3, pad=1, ups=1, N=256, subpix=1)
     assert emu_lib.igemm_route(p1, K.BF16) == "conv3x3_halo_kernel<SUBPIX>"      # source plane narrower than a 32-wide tile
+    sk, w2 = torch.zeros(1, 32, 32, 128, dtype=torch.bfloat16), torch.zeros(256, 128, dtype=torch.bfloat16)
+    op = O.conv(x[:1, :16, :16].contiguous(), w, out[:1, :32, :32].contiguous(), nimg=1, hin=16, win=16, ho=32, wo=32, ks=3, pad=1, ups=1, N=256, subpix=1, k2=(sk, w2, 128))
+    with pytest.raises(Exception, match="second contraction"):      # only the wide-tile sub-pixel form takes k2_a: loud, not silent
+        oc.run_op(emu_lib, op[0], op[1], torch.bfloat16, "cpu")
 
 
 @pytest.mark.parametrize("xcdtn", [None, "0"])
