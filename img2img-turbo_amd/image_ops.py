@@ -62,6 +62,7 @@ def lanczos_coeffs(in_size, out_size):
 
 
 import collections
+import contextlib
 
 _DEV_TABLES = collections.OrderedDict()      # (in, out, device) -> coefficient tables on the device; small LRU: a server fed
 _DEV_TABLES_MAX = 64                         # arbitrary input sizes must not grow device memory without bound
@@ -88,18 +89,22 @@ def lanczos_resize_u8(images, size, lib=None):
     ow, oh = int(size[0]), int(size[1])
     cur = images.contiguous()
     dev = cur.device
+    # the GPU library takes device tensors only, the CPU emulator host tensors only: no silent mismatch
+    assert (lib.backend == "emu") == (dev.type == "cpu"), "library backend %s cannot take a tensor on %s" % (lib.backend, dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
-    for axis, n_in, n_out in ((1, w, ow), (0, h, oh)):          # Pillow's order: horizontal pass, then vertical pass
-        if n_in == n_out:
-            continue
-        ksize, bounds, coeffs = _tables(n_in, n_out, dev)
-        hin, win = cur.shape[1], cur.shape[2]
-        out = torch.empty((n, hin, n_out, c) if axis == 1 else (n, n_out, win, c), dtype=torch.uint8, device=dev)
-        p = _capi.ResizeU8Params()
-        p.src, p.dst, p.n, p.hin, p.win, p.c = cur.data_ptr(), out.data_ptr(), n, hin, win, c
-        p.axis, p.nout, p.ksize, p.bounds, p.coeffs = axis, n_out, ksize, bounds.data_ptr(), coeffs.data_ptr()
-        lib.check(lib.lib.i2i_resize_u8(C.addressof(p), 0, stream))
-        cur = out
+    # the launches go to the GPU that owns the images even when another one is current
+    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
+        for axis, n_in, n_out in ((1, w, ow), (0, h, oh)):          # Pillow's order: horizontal pass, then vertical pass
+            if n_in == n_out:
+                continue
+            ksize, bounds, coeffs = _tables(n_in, n_out, dev)
+            hin, win = cur.shape[1], cur.shape[2]
+            out = torch.empty((n, hin, n_out, c) if axis == 1 else (n, n_out, win, c), dtype=torch.uint8, device=dev)
+            p = _capi.ResizeU8Params()
+            p.src, p.dst, p.n, p.hin, p.win, p.c = cur.data_ptr(), out.data_ptr(), n, hin, win, c
+            p.axis, p.nout, p.ksize, p.bounds, p.coeffs = axis, n_out, ksize, bounds.data_ptr(), coeffs.data_ptr()
+            lib.check(lib.lib.i2i_resize_u8(C.addressof(p), 0, stream))
+            cur = out
     return cur
 
 
