@@ -375,3 +375,25 @@ def test_data_parallel_forward_two_ranks_gloo(tmp_path, emu_lib):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_E2E_OK" in outs[0]
+
+
+def test_product_and_oracle_twins_of_arch_and_synth_agree():
+    """The product never imports oracle/, so the architecture tables and the synthetic-weight generator exist twice
+    (img2img_turbo_amd/{arch,synth}.py for bench.py / smoke(), oracle/{arch,synth}.py for the checker).  They must stay the
+    same: every architecture constant, every state-dict key and every tensor bit, for both models."""
+    import oracle
+    from oracle.synth import make_cyclegan_weights as o_cg, make_pix2pix_weights as o_p2p
+    from img2img_turbo_amd import arch as parch
+    from img2img_turbo_amd.synth import make_cyclegan_weights as p_cg, make_pix2pix_weights as p_p2p
+    for name in ("TINY_UNET", "TINY_VAE", "SD_TURBO_UNET", "SD_TURBO_VAE"):
+        assert vars(getattr(oracle, name)) == vars(getattr(parch, name)), name
+    a, b = o_p2p(oracle.TINY_UNET, oracle.TINY_VAE, seed=3, sketch=True), p_p2p(parch.TINY_UNET, parch.TINY_VAE, seed=3, sketch=True)
+    c, d = o_cg(oracle.TINY_UNET, oracle.TINY_VAE, rank_unet=16), p_cg(parch.TINY_UNET, parch.TINY_VAE, rank_unet=16)
+    for x, y in ((a, b), (c, d)):
+        for part in ("unet", "vae", "vae_b2a"):
+            sx, sy = getattr(x, part, None), getattr(y, part, None)
+            assert (sx is None) == (sy is None), part
+            if sx is not None:
+                assert list(sx) == list(sy), part
+                assert all(torch.equal(sx[k], sy[k]) for k in sx), part
+        assert x.unet_scaling == y.unet_scaling and x.vae_scaling == y.vae_scaling
