@@ -36,7 +36,8 @@ CPU_BASELINE_THREADS = 16
 CPU_BASELINE_TIMED = 2        # + 1 warm-up: ~30 s of CPU work in the default run
 PER_OP_PATH = None
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_conv3x3_halo.json")   # tools/pmc_traffic.py, PMC passes of THIS command
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_conv3x3.json")   # tools/pmc_traffic.py, PMC passes of THIS command (every conv3x3_* launch)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
 def synth_inputs(kind, B, size, cross_dim, lat, seed):
@@ -69,20 +70,25 @@ def source_hash():
 
 def kernel_roofline(plan, dtype_name, reps=2):
     """HIP-event time of every launch of the program (i2i_run_timed: events recorded on the stream the kernels
-    run on), grouped by the HIP kernel each op resolves to (plan.op_kernel).  The dominant kernel is the halo-tiled
-    3x3 convolution (csrc/conv3x3.hip): `achieved` = its ALGORITHMIC FLOPs (2*9*Cin*Cout per output pixel, SURVEY
-    Appendix B) / its measured time; the sub-pixel upsampler launches execute 4/9 of their algorithmic MACs."""
+    run on), grouped by the HIP kernel each op resolves to (plan.op_kernel = i2i_igemm_route for the contractions).
+    The dominant family is the 3x3 stride-1 convolution: `conv3x3_w32_kernel` (csrc/conv3x3_w32.hip, wide tiles on
+    32x32x16 MFMA, incl. its sub-pixel Upsample2D form) plus `conv3x3_halo_kernel` (csrc/conv3x3.hip) for the planes /
+    channel counts the wide tiles do not take.  `achieved` = the family's ALGORITHMIC FLOPs (2*9*Cin*Cout per output
+    pixel) / its measured time; `executed` prices the sub-pixel launches at the 4/9 of the 3x3 MACs
+    the matrix pipe really runs (plan.op_flops_exec).  Every other MFMA family gets the same two numbers in
+    `kernel_breakdown_ms` (attention: 4*heads*Tq*Tk*d per image)."""
     ms = None
     for _ in range(reps):
         cur = plan.run_timed()
         ms = cur if ms is None else [min(a, b) for a, b in zip(ms, cur)]
     tot = sum(ms)
     fam = {}
-    for name, t, fl in zip(plan.op_kernel, ms, plan.op_flops):
-        f = fam.setdefault(name, [0.0, 0.0, 0])
+    for name, t, fl, fx in zip(plan.op_kernel, ms, plan.op_flops, plan.op_flops_exec):
+        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
         f[0] += t
         f[1] += fl
         f[2] += 1
+        f[3] += fx
     if PER_OP_PATH:
         rows = sorted(((t, label, kn, fl) for (opc, _dt, _p, label), kn, t, fl in zip(plan.prog.ops, plan.op_kernel, ms, plan.op_flops)), reverse=True)
         with open(PER_OP_PATH, "w") as f:
@@ -93,8 +99,8 @@ def kernel_roofline(plan, dtype_name, reps=2):
     f3 = sum(fam[k][1] for k in halo)
     n3 = sum(fam[k][2] for k in halo)
     achieved = f3 / (t3 * 1e-3) / 1e12
-    # the sub-pixel upsampler form executes 4/9 of the algorithmic FLOPs of upsample + 3x3 conv: report the matrix-pipe rate too
-    f3x = sum(fam[k][1] * (4.0 / 9.0 if "<SUBPIX>" in k else 1.0) for k in halo)
+    # the sub-pixel upsampler form executes 4/9 of the 3x3 MACs of upsample + conv (a folded 1x1 skip conv in full): the matrix-pipe rate
+    f3x = sum(fam[k][3] for k in halo)
     executed = f3x / (t3 * 1e-3) / 1e12
     peak = PEAK_TF[dtype_name]
     traffic, traffic_src = None, None
@@ -117,14 +123,16 @@ def kernel_roofline(plan, dtype_name, reps=2):
             "traffic_source": traffic_src,
             "launches": n3, "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),
             "algorithmic_flops_per_launch": f3 / n3, "executed_mfma_flops_per_step": getattr(plan, "halo_flops_real", None)}
-    breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None}
+    breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None,
+                     "frac_of_mfma_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4) if v[1] else None}
                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     return roof, breakdown, tot
 
 
 def cpu_baseline(a, weights, x, cap, eps, noise):
     """The CPU oracle (pure-PyTorch fp32 restatement of the reference path, unmerged LoRA) timed on this host's cores on a
-    bounded sample: image 0 of the benchmarked batch, ONE forward, no warm-up.  Returns (record, oracle image)."""
+    bounded sample: image 0 of the benchmarked batch, one warm-up forward + the median of CPU_BASELINE_TIMED timed ones,
+    CPU_BASELINE_THREADS threads.  Returns (record, oracle image)."""
     from oracle.pipeline import ModelWeights, cyclegan_forward, pix2pix_forward
     mw = ModelWeights(weights.unet, weights.vae, weights.unet_arch, weights.vae_arch, weights.unet_scaling, weights.vae_scaling,
                       weights.vae_b2a)
@@ -313,6 +321,29 @@ def main():
                 lat.append((time.perf_counter() - t) * 1e3)
             rec["latency_bs1_ms_p50"] = round(statistics.median(lat), 3)
             rec["images_per_s_bs1"] = round(1e3 / statistics.median(lat), 2)
+            # BASELINE's metric names bs = 1 / 8 / 32: p50 of one synchronous batch (submit -> all images of the batch done)
+            # and the per-image share of it; deterministic pix2pix / cyclegan plans only differ in B
+            for lb in (8, 32):
+                if a.size != 512 or a.arch != "sd-turbo":
+                    break
+                if lb == B:
+                    pb = plan
+                else:
+                    pb = (model.get_plan(lb, a.size, a.size, direction=a.direction) if a.model == "cyclegan" else
+                          model.get_plan(lb, a.size, a.size, stochastic=a.stochastic, r=a.gamma))
+                    xb, _, eb, nb = synth_inputs(kind, lb, a.size, ua.cross_attention_dim, va.latent_channels, 1234 + cfg)
+                    model.stage(pb, xb.to(dev), cap.to(dev), eb.to(dev), nb.to(dev) if a.stochastic else None)
+                for _ in range(2):
+                    pb.replay()
+                torch.cuda.synchronize()
+                lat = []
+                for _ in range(15):
+                    t = time.perf_counter()
+                    pb.replay()
+                    torch.cuda.synchronize()
+                    lat.append((time.perf_counter() - t) * 1e3)
+                rec["latency_bs%d_ms_p50" % lb] = round(statistics.median(lat), 3)
+                rec["latency_bs%d_ms_per_image_p50" % lb] = round(statistics.median(lat) / lb, 3)
         if not a.no_cpu_baseline:
             cb, ref = cpu_baseline(a, weights, x, cap, eps, noise)
             rec["cpu_baseline"] = cb

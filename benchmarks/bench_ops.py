@@ -42,6 +42,11 @@ SHAPES = [  # (name, cin, cout, H, W, ks, stride, ups, gn)
     ("unet lin 1280->10240 T256", 1280, 10240, 16, 16, 1, 1, 0, 0),
     ("unet lin 5120->1280 T256", 5120, 1280, 16, 16, 1, 1, 0, 0),
     ("vae lin 512->1024 T4096", 512, 1024, 64, 64, 1, 1, 0, 0),
+    ("vae lin 512->512 T4096", 512, 512, 64, 64, 1, 1, 0, 0),
+    ("vae sc 256->128@512 1x1", 256, 128, 512, 512, 1, 1, 0, 0),
+    ("vae sc 512->256@256 1x1", 512, 256, 256, 256, 1, 1, 0, 0),
+    ("unet lin 640->640 T1024", 640, 640, 32, 32, 1, 1, 0, 0),
+    ("unet lin 1280->1280 T256", 1280, 1280, 16, 16, 1, 1, 0, 0),
 ]
 
 
@@ -59,6 +64,7 @@ def main():
     ap.add_argument("--subpix", action="store_true", help="upsampler shapes (ups = 1) in the sub-pixel form the product uses ([4][N][2][2][cin] weights)")
     ap.add_argument("--res", action="store_true", help="add a residual tensor in the epilogue (the resnets' conv2)")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
+    ap.add_argument("--geglu", action="store_true", help="1x1 shapes with N % 32 == 0: GEGLU epilogue (ff.net.0 of the transformer blocks; output N/2 columns)")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = 157.3 if a.dtype == "f32" else 2500.0
@@ -75,7 +81,8 @@ def main():
         if sp:
             w = (torch.randn(4 * cout, 4 * cin, device=dev) / math.sqrt(4 * cin)).to(dt)
         ho, wo = (H << ups) // stride, (W << ups) // stride
-        coutp = (cout + 7) // 8 * 8
+        gg = 1 if (a.geglu and ks == 1 and cout % 32 == 0) else 0
+        coutp = (cout // 2 if gg else (cout + 7) // 8 * 8)
         out = torch.empty(B, ho, wo, coutp, device=dev, dtype=dt)
         bias = torch.randn(cout, device=dev)
         resid = torch.randn(B, ho, wo, coutp, device=dev).to(dt) if a.res else None
@@ -90,7 +97,7 @@ def main():
             for _ in range(a.iters + 1):
                 prog.add(*_op(O.conv(x, w, out, nimg=B, hin=H, win=W, ho=ho, wo=wo, ks=ks, stride=stride, pad=ks // 2, ups=ups,
                                       N=cout, gn_ss=ss, act=1 if gn else 0, bias=bias, tile=tile, splitk=sk, ws=ws, subpix=sp,
-                                      res=resid, ldr=coutp if a.res else None), dt))
+                                      res=resid, ldr=coutp if a.res else None, geglu=gg, ldc=coutp), dt))
             prog.freeze()
             try:
                 ms = lib.run_timed(prog, torch.cuda.current_stream().cuda_stream)[1:]
@@ -100,9 +107,9 @@ def main():
             t = sorted(ms)[len(ms) // 2]
             fl = 2.0 * B * ho * wo * cout * ks * ks * cin
             tf = fl / (t * 1e-3) / 1e12
-            rec = dict(name=name, tile=tile, splitk=sk, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
+            rec = dict(name=name + (" geglu" if gg else ""), tile=tile, splitk=sk, ms=t, tflops=tf, frac=tf / peak, dtype=a.dtype, batch=B)
             res.append(rec)
-            print("%-32s tile %d sk %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (name, tile, sk, t, tf, 100 * tf / peak), flush=True)
+            print("%-32s tile %d sk %d  %8.3f ms  %8.1f TF  (%.1f%% of peak)" % (rec["name"], tile, sk, t, tf, 100 * tf / peak), flush=True)
             if a.trace:
                 tr = ws.view(-1, 16).cpu().double()
                 tr = tr[tr.sum(1) > 0]

@@ -4,7 +4,7 @@
 #   1. the bench line of the headline configuration (cfg 2) with the CPU oracle beside it and the parity of image 0
 #   2. rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / total / average)
 #   3. HBM traffic of the halo conv launches: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), corrected per
-#      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3_halo.json keyed on the kernel-source hash
+#      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3.json keyed on the kernel-source hash
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
 TAG=${1:-r3}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
@@ -14,8 +14,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -o write -- $CMD > /dev/null 2> $O/${TAG}_write.err
 F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/${TAG}_write -name "*counter_collection.csv" | head -1)
 python tools/pmc_traffic.py $F $W conv3x3_ --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
-    --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3_halo.json
-cp $O/${TAG}_traffic_conv3x3_halo.json profiles/traffic_conv3x3_halo.json
+    --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3.json
+cp $O/${TAG}_traffic_conv3x3.json profiles/traffic_conv3x3.json
 python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
 python bench.py --batch 1 --no-cpu-baseline > $O/${TAG}_bench_bs1.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --batch 32 --no-cpu-baseline --steps 20 > $O/${TAG}_bench_bs32.json 2>> $O/${TAG}_bench_bs8.err
@@ -32,7 +32,7 @@ except Exception as e:
 PY
 done
 head -8 $O/${TAG}_bench_bs8_kernel_stats.csv | cut -c1-180
-cat $O/${TAG}_traffic_conv3x3_halo.json
+cat $O/${TAG}_traffic_conv3x3.json
 # 5. bs=1 latency path: kernel-trace stats of the bs=1 bench (560 launches per forward)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bs1 -o trace -- python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-latency > /dev/null 2> $O/${TAG}_trace_bs1.err
 cp $(find $O/${TAG}_trace_bs1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs1_kernel_stats.csv

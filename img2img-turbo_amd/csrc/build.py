@@ -3,58 +3,100 @@
     python img2img-turbo_amd/csrc/build.py [--force] [-j N]
 
 One object per .hip source (parallel), then one shared library next to this file.  The .so is
-git-ignored but travels to the GPU box with the gpurun snapshot.
+git-ignored but travels to the GPU box with the gpurun snapshot (objects do not: .gpurunignore).
+
+Staleness is decided by CONTENT, not by mtime (a snapshot copy does not keep mtimes): every object and the library
+carry a sidecar ``<file>.srchash`` = sha256 of (the source, the shared headers, the flags).  ``build()`` prints one
+line per object saying whether it was compiled or reused, and one for the link, so a log shows what a call really did.
 """
 import argparse
 import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "gemm_w32.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip",
+           "attention.hip", "capi.hip", "runtime_hip.hip"]
 HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
 LIB = os.path.join(HERE, "libi2i_turbo.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-# per-source flags.  conv3x3_w32: the GroupNorm+SiLU VALU runs in the MFMA shadow at one wave per SIMD, where packed-f32
+# per-source flags.  conv3x3_w32 / gemm_w32: VALU work runs in the MFMA shadow at one wave per SIMD, where packed-f32
 # VALU (v_pk_mul_f32 / v_pk_add_f32, what SLP vectorisation makes of adjacent scalar ops) costs more than two scalar ops
 # (MI355X_MICROARCH.md "price of one filler beside MFMAs")
-EXTRA_FLAGS = {"conv3x3_w32.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv3x3_w32.hip": ["-fno-slp-vectorize"], "gemm_w32.hip": ["-fno-slp-vectorize"]}
 
 
-def _stale(out, deps):
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    for e in extra:
+        h.update(str(e).encode())
+    return h.hexdigest()
+
+
+def _recorded(path):
+    try:
+        with open(path + ".srchash") as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _record(path, digest):
+    with open(path + ".srchash", "w") as f:
+        f.write(digest + "\n")
+
+
+def source_digest(src, defs=()):
+    """What an object depends on: its source, the shared headers, the flags."""
+    return _digest([os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS], FLAGS + EXTRA_FLAGS.get(src, []) + list(defs))
+
+
+def library_digest(defs=()):
+    return _digest([os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in HEADERS],
+                   FLAGS + [EXTRA_FLAGS.get(s, []) for s in SOURCES] + list(defs))
 
 
 def _compile(src, force, bdir="build", defs=()):
     obj = os.path.join(HERE, bdir, src.replace(".hip", ".o"))
-    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
-    if force or _stale(obj, deps):
-        cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
-    return obj
+    want = source_digest(src, defs)
+    if not force and os.path.exists(obj) and _recorded(obj) == want:
+        return obj, "reused"
+    cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    _record(obj, want)
+    return obj, "compiled"
 
 
-def build(force=False, jobs=None, tag=None, defs=()):
+def build(force=False, jobs=None, tag=None, defs=(), verbose=True):
     """tag/defs: an EXPERIMENT build next to the product one (libi2i_turbo_<tag>.so, objects in build_<tag>/), e.g.
-    ``build.py --tag trace --defs=-DI2I_TRACE=1`` (the halo conv's cycle tracer); load it with I2I_LIB=<path> (img2img_turbo_amd._capi)."""
+    ``build.py --tag trace --defs=-DI2I_TRACE=1`` (the conv kernels' cycle tracer); load it with I2I_LIB=<path> (img2img_turbo_amd._capi)."""
     bdir = "build" + ("_" + tag if tag else "")
     lib = LIB if not tag else os.path.join(HERE, "libi2i_turbo_%s.so" % tag)
+    say = (lambda *a: print("[build]", *a, flush=True)) if verbose else (lambda *a: None)
+    want = library_digest(defs)
+    if not force and os.path.exists(lib) and _recorded(lib) == want:
+        say("%s: reused (library matches the sources: %s)" % (os.path.basename(lib), want[:16]))
+        return lib
     os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, bdir, defs), SOURCES))
-    if force or _stale(lib, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        res = list(ex.map(lambda s: _compile(s, force, bdir, defs), SOURCES))
+    for s, (_, how) in zip(SOURCES, res):
+        say("%-18s %s" % (s, how))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [o for o, _ in res]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    _record(lib, want)
+    say("%s: linked (%s)" % (os.path.basename(lib), want[:16]))
     return lib
 
 

@@ -1,0 +1,424 @@
+// Plain GEMM (nn.Linear / 1x1 convolution) on the "wide" operating point of gfx950: 32x32x16 MFMA, one wave per SIMD,
+// wave tiles of 64 (or 32) rows x 160 (or 128) columns.  Replaces, for the 16-bit dtypes, the cuBLAS calls under
+// diffusers' BasicTransformerBlock (attn to_q|k / to_out, GEGLU ff.net.0, ff.net.2), Transformer2DModel.proj_in / proj_out
+// and the 1x1 conv_shortcut of ResnetBlock2D reached from the UNet call at src/pix2pix_turbo.py:199, with bias, residual
+// add and GEGLU folded into the epilogue.  Same contract as igemm.hip for ks == 1:
+//     C[m][n] = epilogue(alpha * sum_k A[m][k] * B[n][k]),   A = [c0 | c1] channel-concatenated token rows, B = weights [N][K].
+//
+// Why a second GEMM engine next to gemm_dma.hip (profiles/r4_pmc_igemm_*): the 16x16x32 / two-waves-
+// per-SIMD engine needs one ds_read_b128 per two MFMAs of 16 matrix cycles and tops out at 500-600 TFLOP/s on these
+// shapes; and its 256x128 / 128x128 tiles do not divide this model's widths (N = 320 * 2^k: a third of the last column
+// tile is padding, 384 tiles on 256 CUs run as 1.5 rounds).  Here
+//   * a k16 step of a 64 x 160 wave tile is 10 MFMAs of 32 matrix cycles against 7 ds_read_b128;
+//   * the workgroup tile is 256 x 160 (or 128 x 160 / 256 x 128 / 128 x 128): 320, 640, 1280, 2560, 5120 and 10240 are
+//     multiples of 160, and at batch 8 the row counts 32768 / 8192 / 2048 make the tile counts multiples of the 256 CUs;
+//   * both operands reach LDS by global_load_lds_dwordx4 in full 128-byte lines (8 rows per 1-KiB piece, XOR swizzle carried
+//     by the per-lane SOURCE address) into a 3-deep ring of 64-wide K stages, waited for with a counted vmcnt; ONE raw
+//     s_barrier per stage, placed before the last k16 step; the DMA pieces of the stage after next are spread over the
+//     following four k16 steps, one per MFMA slot, order pinned with sched_group_barrier;
+//   * MFMA operands swapped (A-operand = weight rows): a lane owns 4 consecutive columns of one row per register quad, quads
+//     are half-exchanged with v_permlane32_swap so that every lane stores (and fetches the residual as) 16 bytes.
+// 16-bit dtypes only; the exact-f32 parity mode, split-K shapes and everything with a gather stay on gemm_dma.hip.
+#include <stdlib.h>
+
+#include "i2i_dev.h"
+#include "launch.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int V> struct icg { static constexpr int value = V; };
+template <int N, class F> __device__ __forceinline__ void static_for_g(F&& f) {
+    if constexpr (N > 0) {
+        static_for_g<N - 1>(f);
+        f(icg<N - 1>{});
+    }
+}
+
+__device__ __forceinline__ int gswz3(int row) { return (row >> 1) & 7; }
+
+// scalar value the optimiser must not look through (emits no instruction)
+#ifdef I2I_EMU
+__device__ __forceinline__ void sopaque(unsigned&) {}
+#else
+__device__ __forceinline__ void sopaque(unsigned& x) { asm volatile("" : "+v"(x)); }
+#endif
+
+__device__ __attribute__((aligned(16))) uint32_t g32_zero16[4] = {0u, 0u, 0u, 0u};   // DMA source of the dummy pieces
+
+constexpr int G32_NW = 4, G32_BK = 64, G32_KQ = 4;       // waves per workgroup (stacked along M), K per stage, k16 steps per stage
+
+// FMW / FNW: 32-row / 32-column fragments per wave.  Workgroup tile = (4 * 32 * FMW) rows x (32 * FNW) columns.
+template <typename T, int FMW, int FNW, int RING, bool GEGLU>
+__global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igemm_params p) {
+    constexpr int NW = G32_NW, BK = G32_BK, KQ = G32_KQ;
+    constexpr int WTM = 32 * FMW, BM = NW * WTM, BN = 32 * FNW;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int PA = BM / 8, PB = BN / 8;               // 1-KiB DMA pieces (8 rows of 128 bytes) per stage
+    static_assert(PA % NW == 0 && PB % NW == 0, "every wave issues the same pieces");
+    constexpr int QA = PA / NW, QB = PB / NW, OPB = QA + QB;
+    constexpr int NMM = FMW * FNW, NRD = FMW + FNW;
+    static_assert(RING >= 2 && RING <= 4, "");
+    typedef typename Elem<T>::chunk_t chunk_t;
+    static_assert(Elem<T>::EPC == 8, "16-bit dtypes only");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order (workgroup b -> XCD b % 8): every XCD gets a contiguous run of tiles.  The SMALLER operand is the
+    // one re-read along a run: column tiles fastest when the weight matrix is the smaller one (N <= M: an XCD's run walks
+    // the weights while its A row blocks stay put), row tiles fastest otherwise (M = 2048 token rows against 10240 weight
+    // rows: the LDS-DMA igemm's column-fastest order re-fetched 853 MB per launch through the fabric for 31 MB of operands,
+    // profiles/r4_pmc_igemm_summary.txt).
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const bool m_fast = p.N > p.M;
+    const int m0 = (m_fast ? bid % ntm : bid / ntn) * BM, n0 = (m_fast ? bid / ntm : bid % ntn) * BN;
+    const int nk = p.K / BK;                              // K % 64 == 0 (host check)
+
+    const char* a0 = (const char*)p.a0;
+    const char* a1 = (const char*)p.a1;
+    const char* bw = (const char*)p.b;
+
+    // ---- DMA pieces of this wave: A pieces pc = wave + q*NW (rows pc*8 .. +7 of the tile), B pieces likewise behind them.
+    // lane -> row pc*8 + (lane>>3), physical chunk lane&7 = source chunk (lane&7) ^ swz(row); with NW == 4 the swizzle term
+    // ((row>>1)&7 = (pc&1)*4 + (lane>>4)) is the same for every piece of a wave.
+    const int r8 = lane >> 3;
+    const unsigned sch16 = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (r8 >> 1))) << 4);      // byte offset of the source chunk in its row
+    unsigned a_row[QA], a_voff[QA], b_voff[QB];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int m = m0 + (wave + q * NW) * 8 + r8;
+        a_row[q] = (unsigned)(m < p.M ? m : p.M - 1);     // clamped rows feed accumulator rows that are never stored
+        a_voff[q] = a_row[q] * ((unsigned)p.lda0 * 2u) + sch16;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        int n = n0 + (wave + q * NW) * 8 + r8;
+        n = n < p.N ? n : p.N - 1;
+        b_voff[q] = (unsigned)n * ((unsigned)p.ldb * 2u) + sch16;
+    }
+    const int s_sw = p.c1 ? p.c0 / BK : nk;               // first stage that reads the second source (c0 % 64 == 0: host check)
+    // One piece of the open window: A pieces 0 .. QA-1, then B pieces.  EVERY window issues its pieces, branch-free (a branch
+    // would split the basic block and un-pin the MFMA / DMA interleave, and the per-wave VMEM counts stay the same in every
+    // window so the counted waits are exact).  The window state -- source bases of the stage being fetched, destination
+    // slot, and an all-ones / all-zeros lane-offset mask -- is set once per stage (open_window); past the last stage the
+    // bases point at a 16-byte zero block and the mask is 0: the pieces then re-fetch those 16 bytes into the slot, which is
+    // dead by then (tail) or never read (prologue), instead of operand rows.
+    const char* zero = (const char*)g32_zero16;
+    const char* w_abase = zero;
+    const char* w_bbase = zero;
+    unsigned w_msk = 0u;
+    char* w_dst = i2i_smem;
+    auto open_window = [&](int s, int slot) __attribute__((always_inline)) {      // s < 0: dummy window
+        const bool on = s >= 0;
+        const int sa = s >= s_sw ? s - s_sw : s;
+        const char* ab = (s >= s_sw ? a1 : a0) + (size_t)(sa < 0 ? 0 : sa) * (BK * 2);
+        w_abase = on ? ab : zero;
+        w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s) * (BK * 2) : zero;
+        w_msk = on ? 0xffffffffu : 0u;
+        w_dst = i2i_smem + slot * STAGE;
+        sopaque(w_msk);                                    // (the ksteps must not be specialised on the window kind)
+    };
+    auto dma_piece = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < QA) glds16_sv(w_abase, a_voff[q] & w_msk, w_dst + (wave + q * NW) * 1024);
+        else glds16_sv(w_bbase, b_voff[q - QA] & w_msk, w_dst + (PA + wave + (q - QA) * NW) * 1024);
+    };
+    auto a_voff_for = [&](bool second) __attribute__((always_inline)) {
+        const unsigned ldb2 = (unsigned)(second ? p.lda1 : p.lda0) * 2u;
+#pragma unroll
+        for (int q = 0; q < QA; ++q) a_voff[q] = a_row[q] * ldb2 + sch16;
+    };
+
+    f32x16 acc[FMW][FNW];
+#pragma unroll
+    for (int i = 0; i < FMW; ++i)
+#pragma unroll
+        for (int j = 0; j < FNW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- per-lane fragment read offsets: row l31 of a 32-row fragment, chunk (2*kk + lh) ^ swz(l31); fragment i / j and the
+    // ring slot are added, the k16 step enters as ^ (kk << 5)
+    const int rd_a = (wave * WTM + l31) * 128 + ((lh ^ gswz3(l31)) << 4);
+    const int rd_b = BM * 128 + l31 * 128 + ((lh ^ gswz3(l31)) << 4);
+
+    chunk_t xf[2][FMW], wf[2][FNW];
+
+    // The batch of stage s + RING (OPB pieces per wave) is issued in the window that opens after barrier P_s: PPS + PREM
+    // pieces in the last k16 step of stage s (window slot 0), PPS in each of the k16 steps 0 .. KQ-2 of stage s + 1.
+    constexpr int PPS = OPB / KQ, PREM = OPB - PPS * KQ;
+    auto win_lo = [](int w) constexpr { return w == 0 ? 0 : PPS + PREM + (w - 1) * PPS; };
+    auto win_n = [](int w) constexpr { return w == 0 ? PPS + PREM : PPS; };
+
+    // One k16 step kk of the stage whose read bases are (rbase_a, rbase_b): the fragment reads of the NEXT k16 step (step nkk
+    // of the bases given) go out beside its first MFMAs, then the DMA pieces [plo, plo+pn) of the open window, one memory
+    // operation per MFMA slot (pinned).
+    auto kstep = [&](auto kkc, int rbase_a, int rbase_b, auto nkkc, auto ploc, auto pnc) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kkc)::value, nkk = decltype(nkkc)::value, plo = decltype(ploc)::value, pn = decltype(pnc)::value;
+        constexpr int cur = kk & 1, nxt = cur ^ 1;
+        const int ra = rbase_a ^ (nkk << 5), rb = rbase_b ^ (nkk << 5);
+#pragma unroll
+        for (int j = 0; j < FNW; ++j) wf[nxt][j] = *(const chunk_t*)(i2i_smem + (rb + j * 4096));
+#pragma unroll
+        for (int i = 0; i < FMW; ++i) xf[nxt][i] = *(const chunk_t*)(i2i_smem + (ra + i * 4096));
+        static_for_g<pn>([&](auto qc) __attribute__((always_inline)) { dma_piece(icg<plo + decltype(qc)::value>{}); });
+#pragma unroll
+        for (int i = 0; i < FMW; ++i)
+#pragma unroll
+            for (int j = 0; j < FNW; ++j) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+        constexpr int TOT = NRD + pn;
+        static_for_g<NMM>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int lo = (TOT * m) / NMM, hi = (TOT * (m + 1)) / NMM;
+            constexpr int nr = (hi < NRD ? hi : NRD) - (lo < NRD ? lo : NRD), nd = (hi - lo) - nr;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (nr > 0) __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
+            if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x010, nd, 0);
+        });
+    };
+
+    // ---- prologue: stages 0 .. RING-2 in flight and the window of stage RING-1 opened exactly as the loop would have left
+    // it behind a barrier "P_-1" (its first PPS + PREM pieces issued here, the rest beside k16 steps 0 .. 2 of stage 0), so
+    // that the VMEM issue stream is the steady-state one from the first barrier on.  Stages past the end are dummy windows
+    // into their own (never read) slots.  Wait for stage 0, publish, first fragments.
+#pragma unroll
+    for (int t = 0; t < RING; ++t) {
+        if (t == s_sw && t < nk) a_voff_for(true);
+        open_window(t < nk ? t : -1, t);
+        if (t < RING - 1) static_for_g<OPB>([&](auto qc) __attribute__((always_inline)) { dma_piece(qc); });
+        else static_for_g<win_n(0)>([&](auto qc) __attribute__((always_inline)) { dma_piece(qc); });
+    }
+    wait_vmcnt<(RING - 2) * OPB + win_n(0)>();
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < FNW; ++j) wf[0][j] = *(const chunk_t*)(i2i_smem + (rd_b + j * 4096));
+#pragma unroll
+    for (int i = 0; i < FMW; ++i) xf[0][i] = *(const chunk_t*)(i2i_smem + (rd_a + i * 4096));
+
+    // ---- K loop.  Stage s sits in slot s % RING.  Barrier P_s stands before the last k16 step of stage s: every wave has
+    // then issued AND completed its last fragment reads of the slot (they run one k16 step ahead), so the slot is free for
+    // stage s + RING; P_s also publishes stage s + 1 (each wave waits for its own pieces with a counted vmcnt just before).
+    // VMEM issue order per wave: [W_0] [W_1] ... (OPB pieces each); at P_s the batch W_{s+RING-1} is complete and everything
+    // up to W_{s+1} must have landed: exactly the RING-2 batches behind it may still fly.
+    int cur = 0;
+    for (int s = 0; s < nk; ++s) {
+        const int nxt = cur + 1 == RING ? 0 : cur + 1;
+        const int ca = rd_a + cur * STAGE, cb = rd_b + cur * STAGE;
+        kstep(icg<0>{}, ca, cb, icg<1>{}, icg<win_lo(1)>{}, icg<win_n(1)>{});
+        kstep(icg<1>{}, ca, cb, icg<2>{}, icg<win_lo(2)>{}, icg<win_n(2)>{});
+        kstep(icg<2>{}, ca, cb, icg<3>{}, icg<win_lo(3)>{}, icg<win_n(3)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(RING - 2) * OPB>();
+        lds_barrier();
+        {                                                  // the window of stage s + RING opens: slot `cur` is free now
+            const int pend = s + RING < nk ? s + RING : -1;
+            if (pend == s_sw && pend >= 0) a_voff_for(true);
+            open_window(pend, cur);
+        }
+        const int na = rd_a + nxt * STAGE, nb = rd_b + nxt * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(icg<3>{}, na, nb, icg<0>{}, icg<win_lo(0)>{}, icg<win_n(0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    wait_vmcnt<0>();                                       // (tail windows: dummy pieces still in flight)
+
+    // ---- epilogue.  acc[i][j][r]: row m0 + wave*WTM + i*32 + l31, column n0 + j*32 + 8*(r>>2) + 4*lh + (r&3).  Register quads
+    // (2*pr, 2*pr+1) are half-exchanged between lanes l and l+32 (widen_pair): the lane then owns the 8 consecutive columns
+    // j*32 + 16*pr + 8*lh .. +7 of its row: 16-byte residual loads and stores.
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    const T* __restrict__ res = (const T*)p.res;
+    T* __restrict__ out = (T*)p.c;
+    if constexpr (!GEGLU) {
+#pragma unroll
+        for (int j = 0; j < FNW; ++j) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int n = n0 + j * 32 + 16 * pr + 8 * lh;
+                const bool nok = n < p.N;                 // N % 8 == 0 (host check): a chunk is inside or outside as a whole
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias_mode == 1 && nok) {
+                    b0 = *(const f32x4*)(p.bias + n);
+                    b1 = *(const f32x4*)(p.bias + n + 4);
+                }
+                chunk_t rr[FMW];
+                if (res) {
+#pragma unroll
+                    for (int i = 0; i < FMW; ++i) {
+                        const int m = m0 + wave * WTM + i * 32 + l31;
+                        const bool ok = nok && m < p.M;
+                        rr[i] = *(const chunk_t*)(res + (ok ? (int64_t)m * p.ldr + n : 0));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FMW; ++i) {
+                    f32x4 qa, qb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qa[r] = acc[i][j][8 * pr + r]; qb[r] = acc[i][j][8 * pr + 4 + r]; }
+                    float v[8];
+                    widen_pair(qa, qb, v);                 // wave-wide: before any lane drops out
+                    const int m = m0 + wave * WTM + i * 32 + l31;
+                    if (!nok || m >= p.M) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = __builtin_fmaf(p.alpha, v[r], b0[r]); v[4 + r] = __builtin_fmaf(p.alpha, v[4 + r], b1[r]); }
+                    if (res) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rr[i][r]);
+                    }
+                    tx8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                    *(tx8*)(out + (int64_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+    } else {
+        // GEGLU: weight rows (and bias) are interleaved per 32 as [16 value rows | 16 gate rows] (packer.geglu_linear), so a
+        // fragment's registers 0..7 are values and 8..15 the gates of the SAME 16 output columns: out = value * gelu(gate),
+        // lane-local; output column block = (n0 + j*32) / 2.
+#pragma unroll
+        for (int j = 0; j < FNW; ++j) {
+            const int nv = n0 + j * 32;                   // packed column of this fragment's first value
+            const bool nok = nv + 32 <= p.N;              // N % 32 == 0 (host check)
+            f32x4 bv[2], bg[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bv[q] = f32x4{0.f, 0.f, 0.f, 0.f}; bg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nok) {
+                    bv[q] = *(const f32x4*)(p.bias + nv + 8 * q + 4 * lh);
+                    bg[q] = *(const f32x4*)(p.bias + nv + 16 + 8 * q + 4 * lh);
+                }
+            }
+            const int no = nv / 2 + 8 * lh;               // output column of the lane's 8 results after the exchange
+            chunk_t rr[FMW];
+            if (res) {
+#pragma unroll
+                for (int i = 0; i < FMW; ++i) {
+                    const int m = m0 + wave * WTM + i * 32 + l31;
+                    const bool ok = nok && m < p.M;
+                    rr[i] = *(const chunk_t*)(res + (ok ? (int64_t)m * p.ldr + no : 0));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FMW; ++i) {
+                f32x4 qa, qb;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = __builtin_fmaf(p.alpha, acc[i][j][4 * q + r], bv[q][r]);
+                        const float g = __builtin_fmaf(p.alpha, acc[i][j][8 + 4 * q + r], bg[q][r]);
+                        const float o = a * gelu_erf_f(g);
+                        if (q == 0) qa[r] = o; else qb[r] = o;
+                    }
+                float v[8];
+                widen_pair(qa, qb, v);
+                const int m = m0 + wave * WTM + i * 32 + l31;
+                if (!nok || m >= p.M) continue;
+                if (res) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rr[i][r]);
+                }
+                tx8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                *(tx8*)(out + (int64_t)m * p.ldc + no) = o;
+            }
+        }
+    }
+}
+
+// tile ids 50..59 (i2i_igemm_params.tile): 50 = auto among the configurations
+//   51: 256 x 160 (64 x 160 per wave)   52: 128 x 160 (32 x 160)   53: 256 x 128 (64 x 128)   54: 128 x 128 (32 x 128)
+struct G32Cfg { int bm, bn; };
+G32Cfg g32_geometry(int cfg) {
+    switch (cfg) {
+        case 51: return {256, 160};
+        case 52: return {128, 160};
+        case 53: return {256, 128};
+        default: return {128, 128};
+    }
+}
+long g32_tiles(const i2i_igemm_params& p, int cfg) {
+    const G32Cfg g = g32_geometry(cfg);
+    return (long)((p.M + g.bm - 1) / g.bm) * ((p.N + g.bn - 1) / g.bn);
+}
+// auto: the column width that divides N (160 for the UNet's 320 * 2^k, else 128); the taller tile when it still gives at
+// least one full round of workgroups
+int g32_cfg(const i2i_igemm_params& p) {
+    if (p.tile >= 51 && p.tile <= 54) return p.tile;
+    const bool w160 = p.N % 160 == 0;
+    const int tall = w160 ? 51 : 53, low = w160 ? 52 : 54;
+    return g32_tiles(p, tall) >= 256 ? tall : low;
+}
+
+template <typename T, int FMW, int FNW>
+int launch_g32(const i2i_igemm_params& p, hipStream_t s) {
+    constexpr int BM = G32_NW * 32 * FMW, BN = 32 * FNW, RING = 3;
+    const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
+    const size_t smem = (size_t)RING * (BM + BN) * 128;
+    if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true>), dim3(tiles), dim3(G32_NW * 64), smem, s, p);
+    else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false>), dim3(tiles), dim3(G32_NW * 64), smem, s, p);
+    return i2i::check_launch("gemm_w32");
+}
+
+template <typename T>
+int launch_g32_t(const i2i_igemm_params& p, hipStream_t s) {
+    switch (g32_cfg(p)) {
+        case 51: return launch_g32<T, 2, 5>(p, s);
+        case 52: return launch_g32<T, 1, 5>(p, s);
+        case 53: return launch_g32<T, 2, 4>(p, s);
+        case 54: return launch_g32<T, 1, 4>(p, s);
+    }
+    return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: unknown tile config %d", p.tile);
+}
+
+}  // namespace
+
+namespace i2i {
+// What the wide GEMM takes: a plain 16-bit contraction (1x1, stride 1, no gather, one z), K and the first source in whole
+// 64-wide stages, 16-byte rows everywhere, per-column bias or none, optional residual / GEGLU; offsets fit 32 bits.
+bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
+    if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
+    if (p.ks != 1 || p.stride != 1 || p.pad != 0 || p.ups != 0 || p.up_h || p.up_w || p.subpix || p.k2_a) return false;
+    if (p.zcount > 1 || p.splitk > 1 || p.gn_ss || p.gn_part || p.act || p.act_out || p.out_f32 || p.bias_mode == 2) return false;
+    const int cin = p.c0 + p.c1;
+    if (p.K != cin || p.K % G32_BK || p.K < G32_BK || (p.c1 && p.c0 % G32_BK)) return false;
+    if (p.lda0 % 8 || (p.a1 && p.lda1 % 8) || p.ldb % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
+    if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b | (uintptr_t)p.c | (uintptr_t)p.res) & 15) return false;
+    if (p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return false;
+    if (p.M < 1 || p.N < 32 || p.N % 8) return false;
+    if (p.geglu && (p.N % 32 || p.bias_mode == 2)) return false;
+    const uint64_t a_bytes = (uint64_t)p.M * (uint64_t)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 2u, b_bytes = (uint64_t)p.N * p.ldb * 2u;
+    if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
+    return true;
+}
+// tile == 0 routing: launches with at least half a round of workgroups in the smallest applicable tile and enough work per
+// tile to amortise the prologue; I2I_GEMM_W32=0 sends everything back to the LDS-DMA igemm (A/B hook, read per launch).
+bool gemm_w32_auto(const i2i_igemm_params& p, int dtype) {
+    const char* e = getenv("I2I_GEMM_W32");
+    if (e && atoi(e) == 0) return false;
+    if (!gemm_w32_eligible(p, dtype)) return false;
+    if (p.N % 160 && p.N % 128) return false;             // a ragged last column tile: the 16x16 engine's narrower tiles fit better
+    return g32_tiles(p, g32_cfg(p)) >= 128;
+}
+int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case I2I_BF16: return launch_g32_t<__bf16>(p, s);
+        case I2I_F16: return launch_g32_t<_Float16>(p, s);
+    }
+    return fail(I2I_ERR_BAD_ARG, "gemm_w32: bad dtype");
+}
+}  // namespace i2i

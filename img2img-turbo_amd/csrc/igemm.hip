@@ -30,7 +30,18 @@ bool conv3x3_w32_auto(const i2i_igemm_params& p, int dtype);        // tile == 0
 int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.hip
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
+bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype);       // gemm_w32.hip
+bool gemm_w32_auto(const i2i_igemm_params& p, int dtype);           // tile == 0: does the wide GEMM take this op?
+int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
+
+namespace {
+// the one routing decision i2i_igemm / i2i_igemm_route / i2i_igemm_gn_parts share for the wide GEMM (tile ids 50..54)
+bool routes_to_gemm_w32(const i2i_igemm_params& p, int dtype) {
+    if (p.tile >= 50 && p.tile <= 59) return i2i::gemm_w32_eligible(p, dtype);
+    return p.tile == 0 && i2i::gemm_w32_auto(p, dtype);
+}
+}  // namespace
 
 namespace {
 
@@ -299,8 +310,11 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     if (p.bias_mode && !p.bias) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bias_mode without bias");
     if (p.geglu && (p.N % 32 || p.out_f32 || p.bias_mode == 2)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad geglu config");
     if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b) & 15) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: operands must be 16-byte aligned");
-    // the conv kernels bring the tile's bias vector into LDS by 16-byte DMA pieces
-    if (p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bias must be 16-byte aligned");
+    // the 3x3 conv kernels bring the tile's bias vector into LDS by 16-byte DMA pieces (the other routes take any 4-byte
+    // aligned bias: the LDS-DMA igemm falls back to scalar bias loads, the wide GEMM is simply not eligible)
+    const bool conv3 = p.ks == 3 && p.stride == 1 && (i2i::conv3x3_halo_eligible(p, dtype) || i2i::conv3x3_w32_eligible(p, dtype));
+    if (conv3 && p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: the 3x3 conv kernels need a 16-byte aligned bias");
+    if (p.bias_mode == 1 && ((uintptr_t)p.bias & 3)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bias must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (dtype < I2I_F32 || dtype > I2I_F16) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
     // 3x3 stride-1 convolutions take the halo-tiled kernel (tile 0 = auto, 10 = force); everything else the generic gather
@@ -308,8 +322,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: gn_part requested but this op cannot produce GroupNorm partials (query i2i_igemm_gn_parts first)");
     if (p.act_out && (!i2i::igemm_dma_eligible(p, dtype) || i2i::conv3x3_halo_eligible(p, dtype)))
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: act_out is implemented by the LDS-DMA igemm only (no GN prologue, aligned output, not a halo conv)");
-    if (p.subpix && !i2i::conv3x3_halo_eligible(p, dtype))
-        return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need the halo conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
+    if (p.subpix && !i2i::conv3x3_halo_eligible(p, dtype) && !i2i::conv3x3_w32_eligible(p, dtype))
+        return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need a 3x3 conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
     if (p.k2_a && !(i2i::conv3x3_w32_eligible(p, dtype) && ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype)))))
         return i2i::fail(I2I_ERR_UNSUPPORTED, "igemm: the second contraction (k2_a) is implemented by the sub-pixel wide-tile conv only (query i2i_igemm_route)");
     const bool w32_forced = p.tile >= 40 && p.tile <= 49;      // 32x32x16-MFMA wide-tile conv (conv3x3_w32.hip)
@@ -318,6 +332,9 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
+    // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..54 = force)
+    if (p.tile >= 50 && p.tile <= 59 && !i2i::gemm_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (wide GEMM) not applicable", p.tile);
+    if (routes_to_gemm_w32(p, dtype)) return i2i::gemm_w32(p, dtype, s);
     // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)
     const bool dma_forced = p.tile >= 20 && p.tile <= 29;
     if (dma_forced && !i2i::igemm_dma_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (LDS-DMA igemm) not applicable", p.tile);
@@ -339,6 +356,7 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32_gn_parts(p, dtype, groups);
     const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
+    if (routes_to_gemm_w32(p, dtype)) return 0;            // the wide GEMM has no statistics epilogue (a planner may force tile 20 instead)
     if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
     return 0;
 }
@@ -351,6 +369,7 @@ extern "C" const char* i2i_igemm_route(const i2i_igemm_params* pp, int dtype) {
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return p.subpix ? "conv3x3_w32_kernel<SUBPIX>" : "conv3x3_w32_kernel";
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return p.subpix ? "conv3x3_halo_kernel<SUBPIX>" : "conv3x3_halo_kernel";
+    if (routes_to_gemm_w32(p, dtype)) return "gemm_w32_kernel";
     if ((p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) && i2i::igemm_dma_eligible(p, dtype)) return "igemm_dma_kernel";
     return "igemm_kernel";
 }

@@ -99,6 +99,7 @@ class ForwardPlan:
         self.taps = {}          # label -> Act of that op's output (meaningful with debug=True)
         self.prog = K.Program()
         self.op_flops = []      # algorithmic FLOPs per op (2*MAC), parallel to prog.ops
+        self.op_flops_exec = [] # FLOPs the matrix pipe executes for the op (sub-pixel upsamplers: 4/9 of the 3x3 part), parallel to prog.ops
         self.op_kernel = []     # HIP kernel each op resolves to (reporting only), parallel to prog.ops
         self.flops = 0
         self.gn_partial = None
@@ -131,14 +132,22 @@ class ForwardPlan:
         self.graph = None
 
     # ------------------------------------------------------------------ helpers
-    def _add(self, op, label, flops=0, kernel=None):
-        """Record one launch.  ``kernel``: which HIP kernel the C dispatcher will pick for an igemm op (the planner
-        mirrors csrc eligibility), used only for reporting (bench.py groups timings by kernel)."""
+    def _add(self, op, label, flops=0, kernel=None, flops_exec=None):
+        """Record one launch.  ``kernel``: which HIP kernel the C dispatcher will pick for an igemm op (i2i_igemm_route),
+        used only for reporting (bench.py groups timings by kernel).  ``flops``: algorithmic FLOPs of the reference op(s)
+        the launch replaces; ``flops_exec``: what the matrix pipe executes when that differs (sub-pixel upsamplers)."""
         self.prog.add(op[0], self.dt, op[1], label)
         self.op_flops.append(flops)
+        self.op_flops_exec.append(flops if flops_exec is None else flops_exec)
         self.op_kernel.append(kernel or {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax",
                                         K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply",
                                         K.OP_IGEMM: "igemm_dma_kernel"}.get(op[0], "boundary/elementwise"))
+
+    def _reroute(self, params, kernel):
+        """Reporting only: the op that owns ``params`` changed its kernel after it was recorded."""
+        for i, (_opc, _dt, p, _label) in enumerate(self.prog.ops):
+            if p is params:
+                self.op_kernel[i] = kernel
 
     def new(self, n, h, w, c, dtype=None):
         t = self.pool.get(n * h * w * c, dtype or self.dtype)
@@ -171,6 +180,15 @@ class ForwardPlan:
         # (i2i_igemm_gn_parts > 0), the streaming re-read of the tensor disappears; only the tiny finalize runs.
         if self.fuse_gn_stats and x1 is None and x.producer is not None and not x.producer.gn_part:
             parts = self.lib.igemm_gn_parts(x.producer, self.dt, groups)
+            if parts == 0 and x.producer.tile == 0 and self.lib.igemm_route(x.producer, self.dt) == "gemm_w32_kernel":
+                # the wide GEMM has no statistics epilogue: when the LDS-DMA igemm can emit the partial sums, keeping the
+                # producer there is cheaper than a streaming gn_stats pass over its output
+                x.producer.tile = 20
+                parts = self.lib.igemm_gn_parts(x.producer, self.dt, groups)
+                if parts == 0:
+                    x.producer.tile = 0
+                else:
+                    self._reroute(x.producer, "igemm_dma_kernel")
             if parts > 0:
                 # dedicated slab (not pooled): it is written by an op recorded EARLIER than this point, so a pooled
                 # buffer could have been lent to an op in between
@@ -278,7 +296,8 @@ class ForwardPlan:
             self._pending_gn.append((op[1], "igemm"))
             op[1].gn_ss = 1  # placeholder, patched in _finish_gn_scratch
         fl = 2 * x.n * ho * wo * pw["n"] * ks * ks * (x.c + c1)
-        kname = self.lib.igemm_route(op[1], self.dt)     # which kernel the C dispatcher picks (reporting only)
+        fl_k2 = 0
+        kname = self.lib.igemm_route(op[1], self.dt)     # which kernel the C dispatcher picks
         out.k2_fused = False
         if k2 is not None and kname == "conv3x3_w32_kernel<SUBPIX>":
             k2x, k2w, k2label = k2
@@ -287,14 +306,17 @@ class ForwardPlan:
                 p_ = op[1]
                 p_.k2_a, p_.k2_b, p_.k2_c, p_.k2_lda, p_.k2_ldb = k2x.t.data_ptr(), k2w["w"].data_ptr(), k2x.c, k2x.c, k2w["w"].shape[1]
                 p_._keep = tuple(p_._keep) + (k2x.t, k2w["w"])
-                fl += 2 * x.n * ho * wo * pw["n"] * k2x.c
+                fl_k2 = 2 * x.n * ho * wo * pw["n"] * k2x.c
                 label = label + " + " + k2label
                 out.k2_fused = True
         if fused and kname == "igemm_kernel":
             kname = "igemm_kernel (register-staged, GN prologue)"
-        if halo:
-            self.halo_flops_real = getattr(self, "halo_flops_real", 0) + (fl * 4 // 9 if subpix else fl)
-        self._add(op, label, fl, kernel=kname)
+        # the sub-pixel form executes 4/9 of the upsample + 3x3 MACs; a folded 1x1 contraction (k2) is executed in full
+        fl_exec = (fl * 4 // 9 if "<SUBPIX>" in kname else fl) + fl_k2
+        fl += fl_k2
+        if kname.startswith("conv3x3_"):
+            self.halo_flops_real = getattr(self, "halo_flops_real", 0) + fl_exec
+        self._add(op, label, fl, kernel=kname, flops_exec=fl_exec)
         self.taps[label] = out
         if gn and not fused:
             self.free(x_in0)
@@ -312,7 +334,7 @@ class ForwardPlan:
                     res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu, splitk=splitk, ws=ws)
         if ws is not None:
             self.pool.put(ws)
-        self._add(op, label, 2 * rows * pw["n"] * cin)
+        self._add(op, label, 2 * rows * pw["n"] * cin, kernel=self.lib.igemm_route(op[1], self.dt))
         self.flops += 2 * rows * pw["n"] * cin
         return out
 
@@ -346,14 +368,15 @@ class ForwardPlan:
         Tp = (T + 7) // 8 * 8                      # row pitch of V^T / scores / probabilities (T itself when the plane is /8-aligned)
         vt = self.pool.get(B * C * Tp, self.dtype)
         self._add(O.bgemm(wv["w"], xn.t, vt, M=C, N=T, Kdim=C, lda=C, ldb=C, ldc=Tp, batch=B, heads=1, a_bs=(0, 0),
-                          b_bs=(T * C, 0), c_bs=(C * Tp, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T")
+                          b_bs=(T * C, 0), c_bs=(C * Tp, 0), bias=wv["b"], bias_mode=2), prefix + ".to_v^T", 2 * B * T * C * C)
         self.flops += 2 * B * T * C * C
         self.free(xn)
         if C == 512 and self.dtype != torch.float32 and T >= 8 and self.fuse_vae_attention:
             # one head of width 512: the wide-head flash kernel (attention.hip), scores never leave the CU
             o = self.pool.get(B * T * C, self.dtype)
             self._add(O.attention(qk, qk[C:], vt, o, batch=B, heads=1, d=C, tq=T, tk=T, ldq=2 * C, ldk=2 * C, ldvt=Tp, ldo=C,
-                                  q_bs=T * 2 * C, k_bs=T * 2 * C, vt_bs=C * Tp, o_bs=T * C, scale=1.0 / math.sqrt(C)), prefix + ".sdpa")
+                                  q_bs=T * 2 * C, k_bs=T * 2 * C, vt_bs=C * Tp, o_bs=T * C, scale=1.0 / math.sqrt(C)), prefix + ".sdpa",
+                      4 * B * T * T * C, kernel="attention_wide_kernel")
             self.flops += 4 * B * T * T * C
             self.pool.put(qk)
             self.pool.put(vt)
@@ -403,7 +426,7 @@ class ForwardPlan:
             assert wv["b"] is None
             vt = self.pool.get(vb * tot * ldvt, self.dtype)
             self._add(O.bgemm(wv["w"], ctx, vt, M=tot, N=tk, Kdim=cd, lda=cd, ldb=cd, ldc=ldvt, batch=vb, heads=1,
-                              a_bs=(0, 0), b_bs=((tk * cd if vb > 1 else 0), 0), c_bs=(tot * ldvt, 0)), "attn2.to_v^T (all modules)")
+                              a_bs=(0, 0), b_bs=((tk * cd if vb > 1 else 0), 0), c_bs=(tot * ldvt, 0)), "attn2.to_v^T (all modules)", 2 * vb * tk * tot * cd)
             self.flops += 2 * vb * tk * tot * cd
             self._zero_init.append(vt)       # (pad columns of V^T only have to be finite)
             self._ckv = dict(k=kall, vt=vt, off=offs, tot=tot, ldvt=ldvt)      # never returned to the pool: read until the last block
@@ -442,12 +465,13 @@ class ForwardPlan:
             wv = pk.conv(p + ".to_v")
             vt, vt_stride = self.pool.get(vb * C * ldvt, self.dtype), C * ldvt
             self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
-                              a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T")
+                              a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T", 2 * vb * tk * C * kv_cin)
             self.flops += 2 * vb * tk * C * kv_cin
         o = self.pool.get(B * T * C, self.dtype)
         if self.flash and d == 64:
             self._add(O.attention(q, k, vt, o, batch=B, heads=heads, d=d, tq=T, tk=tk, ldq=ldq, ldk=ldk, ldvt=ldvt, ldo=C,
-                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(vt_stride if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa")
+                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(vt_stride if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa",
+                      4 * B * heads * T * tk * d, kernel="attention_dma_kernel" if self.dtype != torch.float32 else "attention_kernel")
         else:
             ldp = ldvt
             s = self.pool.get(B * heads * T * tk, torch.float32)

@@ -90,7 +90,9 @@ typedef struct {
     int32_t tile;              /* 0 = auto; else forces a kernel / tile config id (tests / tuning):
                                   1-5 register-staged igemm, 10-19 / 30-39 halo conv3x3, 20-25 LDS-DMA igemm,
                                   40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto; with `subpix` its
-                                  sub-pixel upsampler form) */
+                                  sub-pixel upsampler form), 50-54 wide GEMM (32x32x16 MFMA, gemm_w32.hip; 50 = its own auto,
+                                  51 256x160, 52 128x160, 53 256x128, 54 128x128 workgroup tiles).
+                                  `bias` (bias_mode 1) must be 4-byte aligned; the 3x3 conv routes need it 16-byte aligned */
     int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
     void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */
     float* gn_part;            /* optional: GroupNorm partial sums of the OUTPUT tensor (as stored), written by the
@@ -106,7 +108,7 @@ typedef struct {
                                   UNet's forward_upsample_size path for latent sizes that are not multiples of 8);
                                   0,0 = (2*hin, 2*win).  Source index = min(floor(i * in/up), in-1) as ATen computes it */
     /* Optional SECOND contraction accumulated into the same output before the epilogue:
-     *     out += k2_a[m][0..k2_c) . k2_b[n][0..k2_c)^T,
+     *     acc += k2_a[m][0..k2_c) . k2_b[n][0..k2_c)^T        (so `alpha` scales it like the first contraction),
      * a 1x1 convolution over another NHWC tensor at OUTPUT resolution ([nimg][ho][wo][k2_lda], same dtype; k2_b is [N][k2_ldb]).
      * It is the decoder's `sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) folded into the Upsample2D conv
      * that produces `sample`: no read-modify-write pass over the stream.  k2_c a multiple of 64; taken by the sub-pixel
@@ -257,7 +259,7 @@ int i2i_igemm(const i2i_igemm_params* p, int dtype, void* stream);
  * the kernel that will run it cannot produce GroupNorm partials (planner query; launches nothing). */
 int i2i_igemm_gn_parts(const i2i_igemm_params* p, int dtype, int groups);
 /* Name of the kernel family i2i_igemm() routes this op to ("conv3x3_w32_kernel", "conv3x3_w32_kernel<SUBPIX>",
- * "conv3x3_halo_kernel", "conv3x3_halo_kernel<SUBPIX>", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
+ * "conv3x3_halo_kernel", "conv3x3_halo_kernel<SUBPIX>", "gemm_w32_kernel", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
  * timings by it; the planner does not have to mirror the routing rules).  Launches nothing; never NULL. */
 const char* i2i_igemm_route(const i2i_igemm_params* p, int dtype);
 int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "gemm_w32.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip"]
 OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
          "-Wno-unused-function", "-Wno-unknown-attributes"]

@@ -434,3 +434,43 @@ def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, xcdtn, monkeypatch):
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=64, groups=32, tile=cfg)      # cpg 8
     oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=20, w=40, groups=32, tile=cfg, res=False)   # cpg 4, ragged tiles
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=512, h=8, w=32, groups=32, tile=cfg)       # cpg 16
+
+
+# ---------------------------------------------------------------- wide GEMM (gemm_w32.hip, tile ids 51..54)
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+def test_gemm_w32_tiles(emu_lib, cfg):
+    """nn.Linear / 1x1 conv on 32x32x16 MFMA: ragged row and column tiles, residual + bias + alpha, K of 1 / 2 / 5 stages
+    (shorter than, equal to and longer than the ring), two channel-concatenated sources, both 16-bit types."""
+    bn = 160 if cfg in (51, 52) else 128
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=320, cout=2 * bn + 40, h=9, w=37, ks=1, pad=0, res=True, alpha=0.7, tile=cfg)    # 5 stages, ragged M and N
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cout=bn, h=8, w=16, ks=1, pad=0, tile=cfg)                                   # 1 stage, exact tiles
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=bn, h=5, w=13, ks=1, pad=0, res=True, bias=False, tile=cfg)  # [c0 | c1], source switch at stage 1
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=96, h=7, w=20, ks=1, pad=0, tile=cfg)                                 # 2 stages, one ragged column tile
+
+
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+def test_gemm_w32_geglu(emu_lib, cfg):
+    oc.check_geglu(emu_lib, "cpu", torch.bfloat16, tile=cfg, cff=320, rows=300, cin=128)       # N = 640 packed columns
+    oc.check_geglu(emu_lib, "cpu", torch.float16, tile=cfg, cff=64, rows=70, cin=64)           # N = 128: one (ragged for 160) column tile
+
+
+def test_gemm_w32_routing(emu_lib):
+    """tile == 0: the dispatcher sends a chip-filling plain 16-bit GEMM to the wide kernel and everything it cannot take
+    (fp32, split-K, a GroupNorm prologue, GroupNorm partial sums, odd K) to the other engines; I2I_GEMM_W32=0 switches it off."""
+    import os
+    x = torch.zeros(32768, 320, dtype=torch.bfloat16)
+    w = torch.zeros(320, 320, dtype=torch.bfloat16)
+    out = torch.zeros(32768, 320, dtype=torch.bfloat16)
+    mk = lambda **kw: O.conv(x, w, out, nimg=1, hin=1, win=32768, ho=1, wo=32768, ks=1, **kw)[1]
+    assert emu_lib.igemm_route(mk(), K.BF16) == "gemm_w32_kernel"
+    assert emu_lib.igemm_route(mk(), K.F32) == "igemm_dma_kernel"
+    assert emu_lib.igemm_route(mk(tile=20), K.BF16) == "igemm_dma_kernel"
+    assert emu_lib.igemm_route(mk(splitk=2, ws=torch.zeros(8)), K.BF16) == "igemm_dma_kernel"
+    assert emu_lib.igemm_gn_parts(mk(), K.BF16, 32) == 0 and emu_lib.igemm_gn_parts(mk(tile=20), K.BF16, 80) > 0
+    small = O.conv(x[:512], w, out[:512], nimg=1, hin=1, win=512, ho=1, wo=512, ks=1)[1]
+    assert emu_lib.igemm_route(small, K.BF16) == "igemm_dma_kernel"       # 8 tiles: not worth a wide launch
+    os.environ["I2I_GEMM_W32"] = "0"
+    try:
+        assert emu_lib.igemm_route(mk(), K.BF16) == "igemm_dma_kernel"
+    finally:
+        del os.environ["I2I_GEMM_W32"]

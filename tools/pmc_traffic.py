@@ -1,7 +1,7 @@
 """HBM traffic per launch of one kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) -> JSON for bench.py.
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> conv3x3_halo_kernel \
-        --batch 8 --dtype bf16 --size 512 --source-hash $(python -c 'import bench; print(bench.source_hash())') > profiles/traffic_conv3x3_halo.json
+        --batch 8 --dtype bf16 --size 512 --source-hash $(python -c 'import bench; print(bench.source_hash())') > profiles/traffic_conv3x3.json
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced reads, so fetch bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as is."""
