@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--serial-gather", action="store_true", help="N > 1: gather straight from the plan's output buffer on the launch stream (no overlap with the next replay)")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
     a = ap.parse_args()
     global PER_OP_PATH
@@ -235,14 +236,15 @@ def main():
     else:
         plan = model.get_plan(B, a.size, a.size, stochastic=a.stochastic, r=a.gamma)
     model.stage(plan, x.to(dev), cap.to(dev), eps.to(dev), noise.to(dev) if a.stochastic else None)
-    gather = dp.OutputGather(plan.out, total) if (world > 1 and not a.no_gather) else None
+    # double-buffered: the RCCL gather of step i runs on a side stream beside the replay of step i+1 (dp.OutputGather)
+    gather = dp.OutputGather(plan.out, total, overlap=not a.serial_gather) if (world > 1 and not a.no_gather) else None
     torch.cuda.synchronize()
     setup_s = dp.all_ranks(time.perf_counter() - t_setup, dev)
 
     def step():
         plan.replay()
         if gather is not None:
-            gather()     # dist.gather (async_op=False): the launch stream waits for it, so the next replay cannot overwrite plan.out early
+            gather()     # stages plan.out and gathers it behind an event; --serial-gather: straight from plan.out, the stream waits
 
     for _ in range(a.warmup):
         step()
@@ -251,6 +253,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    if gather is not None:
+        gather.wait()        # the last step's images have arrived on rank 0 inside the timed region
     torch.cuda.synchronize()
     dp.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
@@ -283,6 +287,7 @@ def main():
     if world > 1:
         rec["ms_compute_per_rank"] = ms_compute                     # replay only (no gather), measured after the timed region
         rec["ms_gather"] = round(ms_per_step - max(ms_compute), 3)   # what the RCCL gather adds to the slowest rank's step
+        rec["gather"] = "serial (launch stream waits)" if a.serial_gather else "double-buffered, overlapped with the next replay (side stream)"
         rec["setup_s_per_rank"] = [round(v, 1) for v in setup_s]      # weights built + packed + uploaded + plan, concurrently on the host
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":

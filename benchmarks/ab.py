@@ -1,7 +1,7 @@
 """Same-box, same-process A/B of the whole step with error bars: arms differ by environment variables (planner / launcher
-hooks such as I2I_FUSE_SKIP, I2I_CROSS_KV_MERGED, I2I_W32_XCDTN, I2I_GEMM_W32) and are timed INTERLEAVED.
+hooks such as I2I_FUSE_SKIP, I2I_CROSS_KV_MERGED, I2I_GEMM_W32) and are timed INTERLEAVED.
 
-    python benchmarks/ab.py --arms "I2I_W32_XCDTN=1" "I2I_W32_XCDTN=0" [--repeats 7 --steps 10 --batch 8]
+    python benchmarks/ab.py --arms "I2I_GEMM_W32=1" "I2I_GEMM_W32=0" [--repeats 7 --steps 10 --batch 8]
 
 Every arm gets its own model + plan + captured hipGraph (the hooks are read at plan / capture time), all arms share the
 synthetic weights and inputs.  One repeat = `steps` graph replays of each arm in turn (order rotated per repeat so that

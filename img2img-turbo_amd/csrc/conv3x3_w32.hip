@@ -94,9 +94,12 @@ constexpr int w32_plane(int th, bool subpix = false) { return w32_plane_px(subpi
 // work.  A workgroup owns TH x 32 SOURCE positions of one parity: halo (TH+1) x 33 with its origin shifted by the parity,
 // 4 taps per slab, 2-deep weight ring (4 % 2 == 0 keeps the ring slot a compile-time constant), outputs scattered to
 // (2y+a, 2x+b) as full 256-byte lines.  The Upsample2D conv has neither a norm in front nor a residual.
-template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES, bool SUBPIX = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p, const int xcd_tn) {
+// K2: the launch carries a second contraction (p.k2_a; its code is compiled into these instantiations only, so the plain ones
+// keep their register allocation).
+template <typename T, int TH, int BN, int WM, int WN, bool GN, bool RES, bool SUBPIX = false, bool K2 = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel(const i2i_igemm_params p) {
     static_assert(!SUBPIX || (!GN && !RES), "");
+    static_assert(!K2 || !RES, "a launch with a second contraction has no residual (the contraction replaces it)");
     constexpr int KS = SUBPIX ? 2 : 3, NPAR = SUBPIX ? 4 : 1;
     constexpr int TW = W32_TW, CK = W32_CK, RING = SUBPIX ? 2 : W32_RING, NTAPS = KS * KS;
     static_assert(NTAPS % RING == 0, "the ring slot of a tap is a compile-time constant");
@@ -131,28 +134,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #define W32_ABL(bit) false
 #endif
 
-    // ---- XCD-aware tile id: workgroup b runs on XCD b & 7.  When the number of channel tiles divides 8 (xcd_tn: 1, 2, 4, 8
-    // -- the launcher then sizes the grid as 8 x the longest run) the channel tile is XCD % ntn: every CU of an XCD streams
-    // the SAME BN rows of the weight matrix (512 -> 512: 2.4 MB instead of 4.7 MB against a 4 MB L2; with both channel tiles
-    // on one XCD the weight DMA alone cost 30 % of a kernel, profiles/r3g_w32_ablation.log) and the spatial tiles are split
-    // into 8 / ntn contiguous runs.  Otherwise every XCD gets one contiguous run of (tile, channel tile) pairs.
+    // ---- XCD-aware tile id: workgroup b runs on XCD b & 7; every XCD gets one contiguous run of (spatial tile, channel tile)
+    // pairs, channel tiles fastest, so neighbouring spatial tiles (shared halo rows) and the channel tiles of one spatial tile
+    // (same halo) meet in one L2.  (Round 3 also pinned ONE channel tile per XCD so that each L2 streams half / a quarter of the
+    // weight matrix; the interleaved same-box A/B of round 4 put it at -0.04 +- 0.4 % of a step -- inside the noise -- and it
+    // was removed: profiles/r4_ab_xcdtn_fuse_skip.log.)
     const int pl_h = SUBPIX ? p.hin : p.ho, pl_w = SUBPIX ? p.win : p.wo;       // the plane the tiles walk
     const int tiles_x = (pl_w + TW - 1) / TW, tiles_y = (pl_h + TH - 1) / TH;
     const int ntn = (p.N + BN - 1) / BN;
     int tn, bid;
     {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        if (xcd_tn) {
-            const int nsp = tiles_x * tiles_y * p.nimg * NPAR, ng = 8 / ntn, grp = xcd / ntn;
-            const int q = nsp / ng, r = nsp % ng;
-            if (idx >= q + (grp < r ? 1 : 0)) return;              // (runs differ by one tile: uniform exit of the surplus workgroup)
-            tn = xcd % ntn;
-            bid = (grp < r ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + idx;
-        } else {
-            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-            tn = bid % ntn; bid /= ntn;
-        }
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tn = bid % ntn; bid /= ntn;
     }
     int pa = 0, pb = 0;                                  // output parity (row, column) of this workgroup: fastest tile index
     if (SUBPIX) { pa = (bid >> 1) & 1; pb = bid & 1; bid >>= 2; }
@@ -440,12 +435,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 
     lds_barrier();                                       // every wave is done with the halo planes / the ring: the staging blocks reuse them
 
-    // ---- second contraction (p.k2_a; sub-pixel form only): acc += k2_a[pixel][0..k2_c) . k2_b[n][0..k2_c)^T with the pixels taken at
-    // the OUTPUT positions of this parity -- the decoder's `sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) folded
-    // into the Upsample2D conv that produces `sample`: the 1x1 skip convolution costs 64-channel slabs of one tap here instead of a
-    // read-modify-write pass over the whole stream.  Per slab: weights by LDS-DMA into ring slot 0, the tile's TH x 32 pixels into
-    // the halo planes at (row, column) = tap (0, 0) positions, four k16 steps; the next slab's loads fly under them.
-    if constexpr (SUBPIX) {
+    // ---- second contraction (p.k2_a): acc += k2_a[pixel][0..k2_c) . k2_b[n][0..k2_c)^T with the pixels taken at the OUTPUT
+    // positions of this tile (sub-pixel form: of this parity).  Two users: the decoder's `sample = sample + skip_conv_i(skip *
+    // gamma)` (src/model.py:41-43) folded into the Upsample2D conv that produces `sample`, and a ResnetBlock2D's
+    // `conv_shortcut(x) + conv2(...)` (diffusers resnet.py: output = shortcut(input) + hidden) folded into its conv2 -- the 1x1
+    // convolution costs 64-channel slabs of one tap here instead of a launch of its own plus a write and a re-read of its
+    // output.  Per slab: weights by LDS-DMA into ring slots 0 / 1, the tile's TH x 32 pixels (RAW: no GroupNorm on this operand)
+    // into the halo planes at (row, column) = tap (0, 0) positions, four k16 steps; the next slab's loads fly under them.
+    if constexpr (K2) {
         if (p.k2_a) {
             int t2 = tid;
             opaque(t2);                                   // nothing below shares a value with the staging constants of the main loop
@@ -456,8 +453,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             for (int j = 0; j < HPT; ++j) {
                 const int hp = (t2 >> 3) + j * (NT / 8);
                 const int hy = hp / HW2, hx = hp - hy * HW2;
-                const bool ok = hy < TH && hx < TW && ty0 + hy < p.hin && tx0 + hx < p.win;
-                k2pix[j] = ok ? (unsigned)((2 * (ty0 + hy) + pa) * p.wo + 2 * (tx0 + hx) + pb) * (unsigned)p.k2_lda * (unsigned)sizeof(T) + (unsigned)kc2 * 16u : 0u;
+                const bool ok = hy < TH && hx < TW && ty0 + hy < pl_h && tx0 + hx < pl_w;
+                const int oy2 = SUBPIX ? 2 * (ty0 + hy) + pa : ty0 + hy, ox2 = SUBPIX ? 2 * (tx0 + hx) + pb : tx0 + hx;
+                k2pix[j] = ok ? (unsigned)(oy2 * p.wo + ox2) * (unsigned)p.k2_lda * (unsigned)sizeof(T) + (unsigned)kc2 * 16u : 0u;
                 k2ok |= (ok ? 1u : 0u) << j;
             }
             unsigned k2w[BPW];
@@ -676,21 +674,25 @@ template <typename T, int TH, int BN, int WM, int WN>
 int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
     const int pl_h = p.subpix ? p.hin : p.ho, pl_w = p.subpix ? p.win : p.wo;
     const int nsp = ((pl_w + W32_TW - 1) / W32_TW) * ((pl_h + TH - 1) / TH) * p.nimg * (p.subpix ? 4 : 1), ntn = (p.N + BN - 1) / BN;
-    const bool xcd_off = getenv("I2I_W32_XCDTN") && atoi(getenv("I2I_W32_XCDTN")) == 0;      // A/B / test hook, read per launch
-    const int xcd_tn = (8 % ntn == 0 && !xcd_off) ? 1 : 0;
-    const unsigned tiles = xcd_tn ? 8u * (unsigned)((nsp + 8 / ntn - 1) / (8 / ntn)) : (unsigned)(nsp * ntn);
+    const unsigned tiles = (unsigned)(nsp * ntn);
     const bool gn = p.gn_ss != nullptr;
     const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
     const dim3 g(tiles), b(WM * WN * 64);
     if (p.subpix) {
         const size_t smem_sp = 4 * w32_plane(TH, true) + 1024 + 2 * BN * 128 + BN * 4;        // 2-deep weight ring
-        hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true>), g, b, smem_sp, s, p, xcd_tn);
+        if (p.k2_a) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true, true>), g, b, smem_sp, s, p);
+        else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true, false>), g, b, smem_sp, s, p);
         return i2i::check_launch("conv3x3_w32<SUBPIX>");
     }
-    if (gn && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p, xcd_tn);
-    else if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p, xcd_tn);
-    else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p, xcd_tn);
-    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false>), g, b, smem, s, p, xcd_tn);
+    if (p.k2_a) {        // (eligibility: no residual beside a second contraction)
+        if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false, false, true>), g, b, smem, s, p);
+        else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, false, true>), g, b, smem, s, p);
+        return i2i::check_launch("conv3x3_w32<K2>");
+    }
+    if (gn && p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, true>), g, b, smem, s, p);
+    else if (gn) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, true, false>), g, b, smem, s, p);
+    else if (p.res) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, true>), g, b, smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false>), g, b, smem, s, p);
     return i2i::check_launch("conv3x3_w32");
 }
 
@@ -729,7 +731,7 @@ bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.geglu || p.zcount > 1 || p.bias_mode == 2 || p.out_f32 || p.act_out) return false;
     if (p.c0 % W32_CK || p.c1 % W32_CK || (p.c0 + p.c1) < W32_CK || (p.c0 + p.c1) > W32_MAX_CIN) return false;
     if (p.N < 128 || p.N % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
-    if (p.k2_a && (!p.subpix || !p.k2_b || p.k2_c < W32_CK || p.k2_c % W32_CK || p.k2_lda % 8 || p.k2_ldb % 8 || p.k2_lda < p.k2_c || p.k2_ldb < p.k2_c ||
+    if (p.k2_a && (p.res || !p.k2_b || p.k2_c < W32_CK || p.k2_c % W32_CK || p.k2_lda % 8 || p.k2_ldb % 8 || p.k2_lda < p.k2_c || p.k2_ldb < p.k2_c ||
                    (((uintptr_t)p.k2_a | (uintptr_t)p.k2_b) & 15))) return false;
     if (p.subpix) {      // sub-pixel upsampler: tiles walk the SOURCE plane, weights [4 parities][N][4*cin]; no norm, no residual
         if (p.ups != 1 || p.up_h || p.up_w || p.gn_ss || p.act || p.res || p.ldb != 4 * (p.c0 + p.c1)) return false;

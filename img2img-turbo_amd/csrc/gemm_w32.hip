@@ -405,13 +405,17 @@ bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
     return true;
 }
-// tile == 0 routing: launches with at least half a round of workgroups in the smallest applicable tile and enough work per
-// tile to amortise the prologue; I2I_GEMM_W32=0 sends everything back to the LDS-DMA igemm (A/B hook, read per launch).
+// tile == 0 routing (measured per shape against the LDS-DMA igemm, same box: profiles/r4b_bench_ops_gemm.log): the UNet's
+// projections -- widths that are multiples of 160, K of at least five stages -- with at least half a round of workgroups
+// win by 1.2 - 2x (1280 -> 10240 @ 2048 rows: 0.132 -> 0.065 ms); the VAE's 1x1 convolutions (K = 128 .. 512 over 0.5 - 2 M
+// rows: HBM-bound streams of short tiles) are 10 - 40 % FASTER on the LDS-DMA igemm's persistent tile stream and stay there.
+// I2I_GEMM_W32=0 sends everything back to the LDS-DMA igemm, =2 takes every eligible op (A/B and test hook, read per launch).
 bool gemm_w32_auto(const i2i_igemm_params& p, int dtype) {
     const char* e = getenv("I2I_GEMM_W32");
-    if (e && atoi(e) == 0) return false;
-    if (!gemm_w32_eligible(p, dtype)) return false;
-    if (p.N % 160 && p.N % 128) return false;             // a ragged last column tile: the 16x16 engine's narrower tiles fit better
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || !gemm_w32_eligible(p, dtype)) return false;
+    if (mode == 2) return true;
+    if (p.N % 160 || p.K < 5 * G32_BK) return false;
     return g32_tiles(p, g32_cfg(p)) >= 128;
 }
 int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {

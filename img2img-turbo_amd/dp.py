@@ -39,39 +39,85 @@ def shard(t, rank, world):
 
 class OutputGather:
     """Gather of the finished images to ``dst`` into buffers allocated ONCE (the timed loop of bench.py / a serving loop
-    calls it every step): ``local`` is the plan's static output buffer [b_r, ...]; rank ``dst`` owns one
-    [world, max_shard, ...] slab whose per-rank views are the gather list.  Ragged shards are padded to the largest.
+    calls it every step): ``local`` is the plan's static output buffer [b_r, ...]; rank ``dst`` owns [world, max_shard, ...]
+    slabs whose per-rank views are the gather lists.  Ragged shards are padded to the largest.
 
-    ``dist.gather`` with async_op=False makes the CURRENT stream wait for the collective, so a following hipGraph replay
-    on that stream cannot overwrite ``local`` while RCCL still reads it."""
+    ``overlap=False``: ``dist.gather`` straight from ``local`` with async_op=False -- the CURRENT stream waits for the
+    collective, so a following hipGraph replay on that stream cannot overwrite ``local`` while RCCL still reads it; the gather
+    of step i is then serial with the replay of step i+1.
 
-    def __init__(self, local, total, dst=0):
-        self.local, self.total, self.dst = local, total, dst
+    ``overlap=True`` (double-buffered): step i copies ``local`` into staging buffer i % 2 on the compute stream (a device-to-
+    device copy of a few MB), and the collective runs on a side stream behind an event -- the compute stream goes straight on
+    to the replay of step i+1 while RCCL moves step i over xGMI.  Buffer i % 2 (and its slab on ``dst``) is reused at step
+    i+2, after the compute stream has waited for the gather of step i.  ``images()`` / ``wait()`` join the side stream.
+    On CPU tensors (gloo, the tests) there are no streams: same buffers, same alternation, synchronous collectives."""
+
+    def __init__(self, local, total, dst=0, overlap=False):
+        self.local, self.total, self.dst, self.overlap = local, total, dst, overlap
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.sizes = [shard_bounds(total, r, self.world)[1] - shard_bounds(total, r, self.world)[0] for r in range(self.world)]
         mx = max(self.sizes)
-        self.send = local
-        if local.shape[0] != mx:
-            self.send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        self.slab = self.views = None
+        nbuf = 2 if overlap else 1
+        tail = tuple(local.shape[1:])
+        if overlap or local.shape[0] != mx:
+            self.send = [torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device) for _ in range(nbuf)]
+        else:
+            self.send = [local]
+        self.slabs = self.views = None
         if self.rank == dst:
-            self.slab = torch.empty((self.world, mx) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-            self.views = [self.slab[r] for r in range(self.world)]
+            self.slabs = [torch.empty((self.world, mx) + tail, dtype=local.dtype, device=local.device) for _ in range(nbuf)]
+            self.views = [[sl[r] for r in range(self.world)] for sl in self.slabs]
+        self.step = 0
+        self.cuda = local.is_cuda
+        if overlap and self.cuda:
+            self.comm = torch.cuda.Stream(device=local.device)
+            self.copied = [torch.cuda.Event() for _ in range(2)]       # staging buffer i filled (compute stream)
+            self.gathered = [None, None]                               # gather out of staging buffer i done (side stream)
+
+    @property
+    def slab(self):
+        """The slab the most recent call gathered into (``dst`` only)."""
+        return None if self.slabs is None else self.slabs[(self.step - 1) % len(self.slabs)]
 
     def __call__(self):
-        """-> on ``dst``: the slab [world, max_shard, ...] (rank r's images are slab[r, :sizes[r]]); None elsewhere."""
-        if self.send is not self.local:
-            self.send[: self.local.shape[0]].copy_(self.local)
-        dist.gather(self.send, self.views, dst=self.dst)
-        return self.slab
+        """-> on ``dst``: the slab [world, max_shard, ...] this step gathers into (rank r's images are slab[r, :sizes[r]];
+        with overlap=True it is complete only after wait() / images()); None elsewhere."""
+        i = self.step % len(self.send)
+        self.step += 1
+        send = self.send[i]
+        views = self.views[i] if self.views is not None else None
+        if not (self.overlap and self.cuda):
+            if send is not self.local:
+                send[: self.local.shape[0]].copy_(self.local)
+            dist.gather(send, views, dst=self.dst)
+            return self.slabs[i] if self.slabs is not None else None
+        cur = torch.cuda.current_stream(self.local.device)
+        if self.gathered[i] is not None:
+            cur.wait_event(self.gathered[i])            # the gather of step i-2 has read this staging buffer
+        send[: self.local.shape[0]].copy_(self.local)
+        self.copied[i].record(cur)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.copied[i])
+            dist.gather(send, views, dst=self.dst)      # async_op=False: the SIDE stream waits for the collective
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+            self.gathered[i] = ev
+        return self.slabs[i] if self.slabs is not None else None
+
+    def wait(self):
+        """Join the side stream: everything gathered so far is complete for the current stream."""
+        if self.overlap and self.cuda:
+            torch.cuda.current_stream(self.local.device).wait_stream(self.comm)
 
     def images(self):
-        """[total, ...] on ``dst`` in global batch order (a copy only when shards are ragged)."""
+        """[total, ...] on ``dst`` in global batch order, of the most recent step (a copy only when shards are ragged)."""
+        self.wait()
         if self.rank != self.dst:
             return None
+        slab = self.slab
         if len(set(self.sizes)) == 1:
-            return self.slab.reshape((self.total,) + tuple(self.slab.shape[2:]))
-        return torch.cat([self.slab[r, :s] for r, s in enumerate(self.sizes)], dim=0)
+            return slab.reshape((self.total,) + tuple(slab.shape[2:]))
+        return torch.cat([slab[r, :s] for r, s in enumerate(self.sizes)], dim=0)
 
 
 def gather_images(local, total, dst=0):

@@ -189,6 +189,16 @@ class Packer:
                                    b=None if b is None else self._up(b, torch.float32), n=w.shape[0], ks=w.shape[2])
         return self.cache[key]
 
+    def bias_sum(self, name_a, name_b):
+        """fp32 device vector bias_a + bias_b (either may be absent): the bias of a launch that computes both layers at once
+        (a resnet's conv2 with its conv_shortcut folded in as a second contraction).  Biases carry no adapter."""
+        key = ("bias_sum", name_a, name_b)
+        if key not in self.cache:
+            ba, bb = self.base(name_a)[1], self.base(name_b)[1]
+            tot = ba if bb is None else (bb if ba is None else ba + bb)
+            self.cache[key] = None if tot is None else self._up(tot, torch.float32)
+        return self.cache[key]
+
     def conv_subpixel(self, name):
         """Upsample2D conv in sub-pixel form: dict(w=[4*N][4*I] dtype, b, n, ks=3, subpix=True) (see subpixel_weights).
         The form is linear in the 3x3 kernel, so lora_A (itself a 3x3 conv) goes through the same map per parity."""

@@ -148,9 +148,11 @@ class TurboGeneratorBase(torch.nn.Module):
                     pk.set_scale(r, r)
 
     def get_plan(self, B, H, W, stochastic=False, r=1.0, direction="a2b", ctx_batch=1, u8_io=None) -> ForwardPlan:
-        """The cached plan for this shape.  `r` is not part of the key (device addresses do not depend on it): the plan
-        records the r of THIS request and re-applies it whenever it runs (ForwardPlan.before_run), so a caller may hold
-        several plans / r values and interleave their run() / replay()."""
+        """The cached plan for this shape.  `r` is not part of the key (device addresses do not depend on it): ONE plan object
+        per key, which records the r of the most recent get_plan() for that key and re-applies it whenever it runs
+        (ForwardPlan.before_run).  Plans of DIFFERENT keys (a stochastic and a deterministic one, two sizes) can be held and
+        interleaved safely; two r values for the SAME key are the same object -- the last get_plan() wins, so ask again
+        (it is a dictionary lookup) before running with another r."""
         r_plan = float(r) if stochastic else 1.0
         self.set_lora_scale(r_plan)
         key = (B, H, W, self.dtype_, stochastic, direction, ctx_batch, u8_io)

@@ -111,6 +111,7 @@ class ForwardPlan:
         self._ckv = None        # merged cross-attention K / V^T of the UNet (see _cross_kv)
         self.cross_kv_merged = os.environ.get("I2I_CROSS_KV_MERGED", "1") != "0"
         self.fuse_skip = os.environ.get("I2I_FUSE_SKIP", "1") != "0"       # decoder skip convs folded into the upsamplers (A/B hook)
+        self.fuse_shortcut = os.environ.get("I2I_FUSE_SHORTCUT", "1") != "0"   # resnet conv_shortcut folded into conv2 (A/B hook)
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -238,8 +239,9 @@ class ForwardPlan:
              res: Optional[Act] = None, alpha=1.0, out: Optional[Act] = None, geglu=0, out_f32=0, cout_pad=None,
              label="", k2=None) -> Act:
         """One implicit-GEMM launch.  ``gn``: apply the pending GroupNorm scale/shift (+act) to the A operand.
-        ``k2`` = (Act at output resolution, packed 1x1 weights, label): a second contraction folded into this launch when the
-        kernel it routes to takes one (i2i_igemm_params.k2_a); the returned Act then has ``k2_fused`` set."""
+        ``k2`` = dict(x=Act at output resolution, w=packed 1x1 weights, label, [bias], [fallback]): a second contraction folded
+        into this launch when the kernel it routes to takes one (i2i_igemm_params.k2_a); the returned Act then has ``k2_fused``
+        set; otherwise ``fallback()`` (if given) records the separate launch and its output becomes this launch's residual."""
         ks = ks or pw["ks"]
         pad = (ks // 2 if not asym else 0) if pad is None else pad
         hin, win = x.h, x.w
@@ -299,16 +301,29 @@ class ForwardPlan:
         fl_k2 = 0
         kname = self.lib.igemm_route(op[1], self.dt)     # which kernel the C dispatcher picks
         out.k2_fused = False
-        if k2 is not None and kname == "conv3x3_w32_kernel<SUBPIX>":
-            k2x, k2w, k2label = k2
-            bk2 = 64
-            if (k2x.n, k2x.h, k2x.w) == (x.n, ho, wo) and k2x.c % bk2 == 0 and k2w["n"] == pw["n"] and k2w["b"] is None and k2w["w"].shape[1] == k2x.c:
-                p_ = op[1]
+        if k2 is not None:
+            # k2 = dict(x=Act at output resolution, w=packed 1x1 weights, label=..., [bias=fp32 bias to use when fused],
+            #           [fallback=callable -> residual Act when the launch cannot take the contraction])
+            k2x, k2w = k2["x"], k2["w"]
+            p_ = op[1]
+            ok = (kname in ("conv3x3_w32_kernel<SUBPIX>", "conv3x3_w32_kernel") and res is None and k2x.c % 64 == 0 and
+                  (k2x.n, k2x.h, k2x.w) == (x.n, ho, wo) and k2w["n"] == pw["n"] and k2w["w"].shape[1] == k2x.c and
+                  (k2w["b"] is None or k2.get("bias") is not None))
+            if ok:
                 p_.k2_a, p_.k2_b, p_.k2_c, p_.k2_lda, p_.k2_ldb = k2x.t.data_ptr(), k2w["w"].data_ptr(), k2x.c, k2x.c, k2w["w"].shape[1]
-                p_._keep = tuple(p_._keep) + (k2x.t, k2w["w"])
+                keep = (k2x.t, k2w["w"])
+                if k2.get("bias") is not None:          # the folded conv's bias rides in the launch's bias vector (Packer.bias_sum)
+                    p_.bias, p_.bias_mode = k2["bias"].data_ptr(), 1
+                    keep += (k2["bias"],)
+                p_._keep = tuple(p_._keep) + keep
                 fl_k2 = 2 * x.n * ho * wo * pw["n"] * k2x.c
-                label = label + " + " + k2label
+                label = label + " + " + k2["label"]
                 out.k2_fused = True
+            elif k2.get("fallback") is not None:        # the separate launch after all: its output is this launch's residual
+                r_ = k2["fallback"]()
+                p_.res, p_.ldr = r_.t.data_ptr(), r_.c
+                p_._keep = tuple(p_._keep) + (r_.t,)
+                out.k2_residual = r_
         if fused and kname == "igemm_kernel":
             kname = "igemm_kernel (register-staged, GN prologue)"
         # the sub-pixel form executes 4/9 of the upsample + 3x3 MACs; a folded 1x1 contraction (k2) is executed in full
@@ -345,9 +360,20 @@ class ForwardPlan:
         h = self.conv(pk.resnet_conv1(prefix, arch, split), x, x1=x1, gn=True, act=1, label=prefix + ".conv1")
         self.gn_stats(pk, prefix + ".norm2", h, groups, eps)
         if pk.has(prefix + ".conv_shortcut"):
-            sc = self.conv(pk.conv(prefix + ".conv_shortcut", split=split), x, x1=x1, label=prefix + ".conv_shortcut")
-            out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=sc, label=prefix + ".conv2")
-            self.free(sc)
+            # output = conv_shortcut(input) + conv2(...) (diffusers ResnetBlock2D): the 1x1 shortcut rides as a second contraction
+            # of the conv2 launch when the wide-tile conv takes it (no launch of its own, no write + re-read of its output);
+            # otherwise it runs first and conv2 adds its output as the residual.
+            sc_conv = lambda: self.conv(pk.conv(prefix + ".conv_shortcut", split=split), x, x1=x1, label=prefix + ".conv_shortcut")
+            if self.fuse_shortcut and x1 is None and x.c % 64 == 0:
+                k2 = dict(x=x, w=pk.conv(prefix + ".conv_shortcut"), label=prefix + ".conv_shortcut",
+                          bias=pk.bias_sum(prefix + ".conv2", prefix + ".conv_shortcut"), fallback=sc_conv)
+                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, label=prefix + ".conv2", k2=k2)
+                if getattr(out, "k2_residual", None) is not None:
+                    self.free(out.k2_residual)
+            else:
+                sc = sc_conv()
+                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=sc, label=prefix + ".conv2")
+                self.free(sc)
         else:
             assert x1 is None
             out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=x, label=prefix + ".conv2")
@@ -639,7 +665,7 @@ class ForwardPlan:
             if i < len(rboc) - 1:
                 # the NEXT block's `sample + skip_conv(skip * gamma)` as a second contraction of this upsampler (when the wide-tile
                 # sub-pixel kernel takes the launch): the 1x1 skip conv was an HBM-bound read-modify-write of the whole stream
-                k2 = (skips[::-1][i + 1], pk.conv(f"decoder.skip_conv_{i + 2}", gamma=True), f"decoder.skip_conv_{i + 2}") if self.fuse_skip else None
+                k2 = dict(x=skips[::-1][i + 1], w=pk.conv(f"decoder.skip_conv_{i + 2}", gamma=True), label=f"decoder.skip_conv_{i + 2}") if self.fuse_skip else None
                 h2 = self.upsample_conv(pk, f"decoder.up_blocks.{i}.upsamplers.0.conv", h, f"decoder.up_blocks.{i}.upsamplers.0.conv", k2=k2)
                 skip_done = bool(getattr(h2, "k2_fused", False))
                 self.free(h)

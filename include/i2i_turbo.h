@@ -111,8 +111,9 @@ typedef struct {
      *     acc += k2_a[m][0..k2_c) . k2_b[n][0..k2_c)^T        (so `alpha` scales it like the first contraction),
      * a 1x1 convolution over another NHWC tensor at OUTPUT resolution ([nimg][ho][wo][k2_lda], same dtype; k2_b is [N][k2_ldb]).
      * It is the decoder's `sample = sample + skip_conv_i(skip * gamma)` (src/model.py:41-43) folded into the Upsample2D conv
-     * that produces `sample`: no read-modify-write pass over the stream.  k2_c a multiple of 64; taken by the sub-pixel
-     * wide-tile conv only (i2i_igemm_route() == "conv3x3_w32_kernel<SUBPIX>"), anything else returns I2I_ERR_UNSUPPORTED. */
+     * that produces `sample` (no read-modify-write pass over the stream), and a ResnetBlock2D's conv_shortcut(input) folded
+     * into its conv2.  k2_c a multiple of 64; taken by the wide-tile conv only (i2i_igemm_route() == "conv3x3_w32_kernel" or
+     * "conv3x3_w32_kernel<SUBPIX>"), anything else returns I2I_ERR_UNSUPPORTED. */
     const void* k2_a; const void* k2_b;
     int32_t k2_c, k2_lda, k2_ldb;
 } i2i_igemm_params;

@@ -46,7 +46,7 @@ def test_pix2pix_r_sweep_one_plan_fp32(emu_lib):
     x, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
     model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.float32, lib=emu_lib)
     plans, packers = None, None
-    for r in (0.4, 1.0, 0.4):
+    for r in (0.4, 1.0, 0.7, 0.4):
         ref = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=r, noise_map=nm)
         out = model(x, caption_enc=cap, eps=eps, deterministic=False, r=r, noise_map=nm)
         assert (out - ref).abs().max().item() < 1e-3, r

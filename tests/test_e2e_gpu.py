@@ -516,6 +516,46 @@ def test_checkpoint_files_to_gpu_forward(gpu_lib, tmp_path, monkeypatch):
         assert report(f"cyclegan from files {direction}", out, cyclegan_forward(ow, xp, capp, epsp, direction=direction)) < 1e-3
 
 
+def test_sd_turbo_size_snapshot_files_to_gpu_forward(gpu_lib, tmp_path, monkeypatch):
+    """Row f4 at REAL scale, once: a synthetic snapshot of the SD-Turbo architecture in the layout of the published one --
+    `unet/diffusion_pytorch_model.fp16.safetensors` (866 M parameters, 1.7 GB) + `vae/...fp16.safetensors` -- and the
+    reference's `.pkl` checkpoint dict (LoRA factors, skip convs; src/pix2pix_turbo.py:221-229) are written to disk and read
+    back through the product's own readers: `Pix2Pix_Turbo(pretrained_path=...)` + `.half()` (src/inference_paired.py:31-35).
+    Exercises what the tiny-architecture file test cannot: the fp16 snapshot -> fp32 master -> device-side LoRA merge path
+    with ~5 GB of masters, and the packers' HBM footprint.  Output against the oracle fed from the same files."""
+    from safetensors.torch import save_file
+    from oracle.pipeline import ModelWeights
+    from oracle.synth import split_pix2pix_checkpoint
+    import img2img_turbo_amd.pix2pix_turbo as P
+    from img2img_turbo_amd.weights import from_pix2pix_checkpoint, load_checkpoint_file, load_sd_turbo_base
+
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 7)
+    base_unet, base_vae, ckpt = split_pix2pix_checkpoint(mw)
+    root = tmp_path / "sd-turbo"
+    (root / "unet").mkdir(parents=True)
+    (root / "vae").mkdir()
+    save_file({k: v.half().contiguous() for k, v in base_unet.items()}, str(root / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    save_file({k: v.half().contiguous() for k, v in base_vae.items() if "skip_conv" not in k}, str(root / "vae" / "diffusion_pytorch_model.fp16.safetensors"))
+    torch.save(ckpt, tmp_path / "model.pkl")
+    nbytes = sum(f.stat().st_size for f in root.rglob("*.safetensors"))
+    print(f"[files] snapshot on disk: {nbytes / 1e9:.2f} GB")
+    assert nbytes > 1.7e9
+    del mw, base_unet, base_vae, ckpt
+    monkeypatch.setenv("I2I_SD_TURBO_DIR", str(root))
+    x, cap, eps, _ = make_inputs("canny", 1, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=7)
+    torch.cuda.reset_peak_memory_stats()
+    model = P.Pix2Pix_Turbo(pretrained_path=str(tmp_path / "model.pkl"), device="cuda")
+    model.set_eval()
+    model.half()
+    out = model(x.cuda().half(), caption_enc=cap.cuda(), eps=eps.cuda())
+    print(f"[files] peak HBM after load + pack + one forward: {torch.cuda.max_memory_allocated() / 1e9:.2f} GB")
+    u, v = load_sd_turbo_base(str(root))
+    g = from_pix2pix_checkpoint(u, v, load_checkpoint_file(tmp_path / "model.pkl"))
+    ref = pix2pix_forward(ModelWeights(g.unet, g.vae, g.unet_arch, g.vae_arch, g.unet_scaling, g.vae_scaling, g.vae_b2a), x, cap, eps)
+    check("SD-Turbo-size snapshot from files, .half()", out, ref, torch.float16)
+    _free(model)
+
+
 def test_fp16_survives_realistic_magnitudes(gpu_lib):
     """The reference's own fast path is ``.half()`` (src/inference_paired.py:34-35).  fp16 overflows at 65504: the synthetic
     weights (sigma = 1/sqrt(fan_in)) keep every activation O(1) and cannot show a saturation.  Here the VAE activations are

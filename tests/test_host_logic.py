@@ -148,14 +148,27 @@ for step in range(3):
         slabs.append(slab.data_ptr())
         imgs = g.images()
         assert imgs.shape == (4, 3, 2, 2) and torch.all(imgs[:2] == 10.0 * step) and torch.all(imgs[2:] == 10.0 * step + 1), imgs
+# double-buffered form (overlap=True: the gather of step i may run beside the replay of step i+1): the plan's buffer is
+# rewritten right after the call -- BEFORE the images of that step are consumed -- and two staging buffers / slabs alternate
+g2 = dp.OutputGather(even, 4, dst=0, overlap=True)
+slabs2 = []
+for step in range(5):
+    even.fill_(100.0 * step + rank)
+    slab = g2()
+    even.fill_(-1.0)                          # the next replay overwrites the static buffer: the staged copy must be what travels
+    if rank == 0:
+        slabs2.append(slab.data_ptr())
+        imgs = g2.images()
+        assert torch.all(imgs[:2] == 100.0 * step) and torch.all(imgs[2:] == 100.0 * step + 1), (step, imgs)
 dp.barrier()
 if rank == 0:
     assert torch.equal(out, full * 2.0), out
     assert m == float(world)
     assert len(set(slabs)) == 1, "the gather must reuse its buffers"
+    assert len(set(slabs2)) == 2 and slabs2[0] == slabs2[2] == slabs2[4] and slabs2[1] == slabs2[3], slabs2
     print("DP_OK")
 else:
-    assert out is None and g.images() is None
+    assert out is None and g.images() is None and g2.images() is None
 """
 
 

@@ -278,6 +278,8 @@ def test_gn_stats_large_offset_second_pass(emu_lib):
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, h=24, w=20)                             # single launch (small tensor)
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, h=24, w=20, finalize_only=True, nparts=7)
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, c=24, groups=3, h=10, w=12, mean=-40.0, std=0.05)   # odd group count, negative offset
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float16, h=24, w=20, mean=100.0, std=0.2)          # 16-bit inputs (ulp 0.0625 at 100): single launch
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.bfloat16, h=24, w=20, mean=30.0, std=0.3, finalize_only=True, nparts=7)   # bf16 (ulp 0.125 at 30)
 
 
 def test_gn_finalize_many_parts(emu_lib):
@@ -424,16 +426,23 @@ def test_w32_subpixel_upsample_conv(emu_lib, cfg):
         oc.run_op(emu_lib, op[0], op[1], torch.bfloat16, "cpu")
 
 
-@pytest.mark.parametrize("xcdtn", [None, "0"])
 @pytest.mark.parametrize("cfg", [41, 42])
-def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg, xcdtn, monkeypatch):
+def test_w32_conv_epilogue_groupnorm_partials(emu_lib, cfg):
     """The epilogue's GroupNorm partial sums of the STORED output (v_dot2c per channel quad; one slot per tile and group),
-    finished by gn_stats.  xcdtn = 0: the tile order without the channel-tile-per-XCD rule."""
-    if xcdtn:
-        monkeypatch.setenv("I2I_W32_XCDTN", xcdtn)
+    finished by gn_stats."""
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=64, groups=32, tile=cfg)      # cpg 8
     oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=20, w=40, groups=32, tile=cfg, res=False)   # cpg 4, ragged tiles
     oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=512, h=8, w=32, groups=32, tile=cfg)       # cpg 16
+
+
+@pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_conv_second_contraction_plain_form(emu_lib, cfg):
+    """A ResnetBlock2D's `conv_shortcut(input) + conv2(silu(norm2(h)))` in ONE launch: the 1x1 shortcut over the raw block input
+    as the second contraction (k2_a) of the wide-tile 3x3 conv, GroupNorm + SiLU on the first operand only; ragged tiles, one and
+    three slabs of the second operand, and the next norm's partial sums from the same epilogue."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=256, h=18, w=40, gn=True, act=1, tile=cfg, k2c=64)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cout=128, h=9, w=33, gn=True, act=1, tile=cfg, k2c=192, alpha=0.5)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=128, h=16, w=32, tile=cfg, k2c=128, bias=False)
 
 
 # ---------------------------------------------------------------- wide GEMM (gemm_w32.hip, tile ids 51..54)

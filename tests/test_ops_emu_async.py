@@ -32,6 +32,7 @@ def test_w32_conv_waits_and_barriers(async_lib, cfg, order, monkeypatch):
     oc.check_conv_gn_part(async_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=16, w=32, groups=32, tile=cfg)
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=192, cout=136, h=12, w=40, ups=1, subpix=True, tile=cfg)      # sub-pixel form: 4 taps, 2-deep ring, 3 slabs
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=128, h=9, w=40, ups=1, subpix=True, tile=cfg, k2c=128)       # + the folded skip conv (2 slabs)
+    oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=128, h=18, w=40, gn=True, act=1, tile=cfg, k2c=128)          # resnet conv2 + folded conv_shortcut
 
 
 def test_subpixel_and_partials_waits(async_lib):

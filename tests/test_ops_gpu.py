@@ -253,6 +253,23 @@ def test_w32_conv_every_tile_config(gpu_lib, cfg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [41, 42])
+def test_w32_conv_second_contraction(gpu_lib, cfg):
+    """The second contraction (i2i_igemm_params.k2_a) of the wide-tile conv on real asynchrony, both forms: a resnet's
+    conv_shortcut folded into its conv2 (GroupNorm + SiLU on the first operand, raw second operand; the decoder's and the
+    encoder's real shapes) and the decoder's skip conv folded into the sub-pixel upsampler; ragged tiles, 1 / 2 / 3 / 8 slabs of
+    the second operand (the two ring slots it alternates between are reused), bf16 and fp16, repeated with fresh seeds."""
+    for rep in range(3):
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=64, w=96, gn=True, act=1, groups=8, tile=cfg, k2c=256, seed=rep)    # up_blocks.3.resnets.0
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=1, cin=256, cout=256, h=40, w=72, gn=True, act=1, groups=8, tile=cfg, k2c=512, seed=rep)     # up_blocks.2.resnets.0, 8 slabs
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=256, cout=256, h=33, w=65, gn=True, act=1, groups=8, tile=cfg, k2c=128, alpha=0.5, seed=rep)  # ragged, 2 slabs
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=3, cin=64, cout=128, h=24, w=64, tile=cfg, k2c=64, bias=False, seed=rep)                     # no norm, 1 slab
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=36, w=52, ups=1, subpix=True, tile=cfg, k2c=192, seed=rep)          # sub-pixel form, 3 slabs
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=2, cin=256, cout=256, h=32, w=64, ups=1, subpix=True, tile=cfg, k2c=128, seed=rep)
+    oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=64, w=64, groups=32, tile=cfg, res=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [41, 42])
 def test_w32_conv_epilogue_groupnorm_partials(gpu_lib, cfg):
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=256, h=64, w=64, groups=32, tile=cfg)
     oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=1, cin=64, cout=128, h=40, w=72, groups=32, tile=cfg, res=False)
@@ -268,3 +285,5 @@ def test_gn_stats_large_offset_second_pass(gpu_lib):
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=256, w=256, groups=32, nparts=64)         # partial + finalize
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=128, w=128, groups=32, nparts=512, finalize_only=True)
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=1, c=256, h=64, w=64, groups=32, mean=-30.0, std=0.02, nparts=16, finalize_only=True)
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=2, c=128, h=64, w=64, groups=32, mean=100.0, std=0.2)                            # 16-bit inputs
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.bfloat16, n=2, c=128, h=128, w=128, groups=32, mean=30.0, std=0.3, nparts=512, finalize_only=True)
