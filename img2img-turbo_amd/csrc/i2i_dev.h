@@ -77,13 +77,25 @@ __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballo
 // round-off class): one v_rcp_f32 + one v_exp_f32 + 8 FMAs instead of libm's erff (~40 VALU) -- the GEGLU epilogue
 // of the ff.net.0 GEMMs evaluates it 4 times per accumulator fragment and was VALU bound.
 __device__ __forceinline__ float erf_as_f(float x) {
+    // explicit fused multiply-adds: the library is built with -ffp-contract=off (bit-stable reductions), which turned this
+    // Horner chain into 10 multiplies + 7 adds per value -- 32 VALU per GEGLU output measured in the wide GEMM's epilogue,
+    // where the gate activation is the bound of the K = 320 layers.  10 VALU + v_rcp + v_exp now.
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * exp2_fast(-1.44269504088896341f * ax * ax);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float r = __builtin_fmaf(-poly, exp2_fast(ax * (ax * -1.44269504088896341f)), 1.0f);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f)); }
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) with the 1/sqrt 2 folded into the constants of the erf above (p = 0.3275911 / sqrt 2,
+// exponent -x^2 / 2): 12 VALU + v_rcp + v_exp
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.23164189f, ax, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float r = __builtin_fmaf(-poly, exp2_fast(ax * (ax * -0.72134752044448170f)), 1.0f);
+    const float h = 0.5f * x;
+    return __builtin_fmaf(h, copysignf(r, x), h);
+}
 
 // LDS tile geometry common to A and B tiles: rows of 128 bytes = 8 chunks; chunk kc of row r is stored
 // at physical chunk kc ^ ((r >> 1) & 7).  With this XOR a ds_read_b128 wave access (lane -> row l&15,
