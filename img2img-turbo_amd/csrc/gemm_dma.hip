@@ -75,15 +75,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
     const int cin = p.c0 + p.c1;
     const int hin_up = p.up_h ? p.up_h : (p.hin << p.ups), win_up = p.up_w ? p.up_w : (p.win << p.ups);
     const bool gather = p.ks != 1 || p.stride != 1 || p.ups != 0 || p.pad != 0;
-    // gather without upsampling (the stride-2 downsamplers, the split-K 3x3 convs of the small UNet planes): the tap only
-    // shifts the pixel index by the wave-uniform ky*win + kx, and whether a tap falls inside the image is a per-row 9-bit
-    // pair of 3-bit masks (rows, columns) computed once per tile -- a few VALU per DMA piece and K step instead of two bound
-    // checks, two up_src and a multiply
-#ifdef I2I_NO_FAST_GATHER
-    const bool fast_gather = false;      // (A/B build: csrc/build.py --tag nofg --defs=-DI2I_NO_FAST_GATHER=1)
-#else
-    const bool fast_gather = gather && p.ups == 0 && p.up_h == 0 && p.up_w == 0 && p.ks <= 3 && cin >= 8 * Elem<T>::EPC;
-#endif
     const int cin_shift = 31 - __builtin_clz((unsigned)(cin > 0 ? cin : 1));     // log2(cin) when cin is a power of two
 
     // ---- K range of this split ----
@@ -137,24 +128,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                 const int mm = m < p.M ? m : 0;
                 const int img = mm / hw, rem = mm - img * hw;
                 const int oy = rem / p.wo, ox = rem - oy * p.wo;
-                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                if (fast_gather) {
-                    // pixel index of tap (0,0) (may lie outside: only taps whose mask bit is set are dereferenced) + validity mask
-                    // (row mask in bits 0..2, column mask in bits 8..10: tap (ky, kx) is inside iff both bits are set)
-                    pc_off[q] = (unsigned)(img * p.hin * p.win + iy0 * p.win + ix0);
-                    int vm = 0;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        vm |= ((unsigned)(iy0 + t) < (unsigned)p.hin ? 1 : 0) << t;
-                        vm |= ((unsigned)(ix0 + t) < (unsigned)p.win ? 1 : 0) << (8 + t);
-                    }
-                    pc_y[q] = m < p.M ? vm : 0;
-                    pc_x[q] = 0;
-                } else {
-                    pc_off[q] = (unsigned)(img * p.hin * p.win);              // pixel index of the image origin
-                    pc_y[q] = m < p.M ? iy0 : -(1 << 28);
-                    pc_x[q] = ix0;
-                }
+                pc_off[q] = (unsigned)(img * p.hin * p.win);              // pixel index of the image origin
+                pc_y[q] = m < p.M ? oy * p.stride - p.pad : -(1 << 28);
+                pc_x[q] = ox * p.stride - p.pad;
             }
         } else {
             const int row = (pc - PA) * 8 + r8;
@@ -197,10 +173,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
                     const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;
                     const unsigned pix = pc_off[q] + (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
                     src = ok ? a0 + (pix * ((unsigned)p.lda0 * (unsigned)sizeof(T)) + (unsigned)ci * (unsigned)sizeof(T)) : zero;
-                } else if (fast_gather) {
-                    const bool ok = kok && ((pc_y[q] >> ky) & (pc_y[q] >> (8 + kx)) & 1);
-                    const unsigned pix = pc_off[q] + (unsigned)(ky * p.win + kx);
-                    src = ok ? abase + (pix * lda_b + pc_chunk[q] * 16u) : zero;
                 } else {
                     const int iy = pc_y[q] + ky, ix = pc_x[q] + kx;
                     const bool ok = kok && (unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up;

@@ -342,11 +342,13 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
 
 // tile ids 50..59 (i2i_igemm_params.tile): 50 = auto among the configurations
 //   51: 256 x 160 (64 x 160 per wave)   52: 128 x 160 (32 x 160)   53: 256 x 128 (64 x 128)   54: 128 x 128 (32 x 128)
+//   55 / 56: 128 x 160 / 128 x 128 with a 2-deep ring (72 / 64 KiB of LDS, under 256 registers): TWO workgroups per CU, so that
+//            one's epilogue (the GEGLU gate activation is ~1.4x the MFMA time of a K = 320 tile) runs beside the other's K loop
 struct G32Cfg { int bm, bn; };
 G32Cfg g32_geometry(int cfg) {
     switch (cfg) {
         case 51: return {256, 160};
-        case 52: return {128, 160};
+        case 52: case 55: return {128, 160};
         case 53: return {256, 128};
         default: return {128, 128};
     }
@@ -355,18 +357,26 @@ long g32_tiles(const i2i_igemm_params& p, int cfg) {
     const G32Cfg g = g32_geometry(cfg);
     return (long)((p.M + g.bm - 1) / g.bm) * ((p.N + g.bn - 1) / g.bn);
 }
-// auto: the column width that divides N (160 for the UNet's 320 * 2^k, else 128); the taller tile when it still gives at
-// least one full round of workgroups
+// auto (measured per shape, same box: profiles/r4b_bench_ops_gemm_w32_vs_dma.log, r4e_bench_ops_*.log):
+//   * GEGLU with K < 1280: the gate activation costs more issue time than the tile's MFMAs -> the two-workgroups-per-CU
+//     form (55), whose epilogues run beside the other workgroup's K loop (320 -> 2560 @ 32768 rows: 0.113 -> 0.097 ms);
+//   * the tall tile (256 rows) when it still gives a full round of workgroups;
+//   * otherwise the 128-row tile whose column width (160 / 128, whichever divide N) fills more of its last round
+//     (5120 -> 1280 @ 2048 rows: 160 tiles of 128 x 128 beat 128 tiles of 128 x 160, 0.045 vs 0.050 ms).
 int g32_cfg(const i2i_igemm_params& p) {
-    if (p.tile >= 51 && p.tile <= 54) return p.tile;
-    const bool w160 = p.N % 160 == 0;
-    const int tall = w160 ? 51 : 53, low = w160 ? 52 : 54;
-    return g32_tiles(p, tall) >= 256 ? tall : low;
+    if (p.tile >= 51 && p.tile <= 56) return p.tile;
+    const bool w160 = p.N % 160 == 0, w128 = p.N % 128 == 0;
+    if (p.geglu && w160 && p.K < 1280) return 55;
+    const int tall = w160 ? 51 : 53;
+    if (g32_tiles(p, tall) >= 256) return tall;
+    auto fill = [&](int cfg) { const long t = g32_tiles(p, cfg); return (double)t / (double)(((t + 255) / 256) * 256); };
+    if (w160 && w128) return fill(54) > fill(52) ? 54 : 52;
+    return w160 ? 52 : 54;
 }
 
-template <typename T, int FMW, int FNW>
+template <typename T, int FMW, int FNW, int RING = 3>
 int launch_g32(const i2i_igemm_params& p, hipStream_t s) {
-    constexpr int BM = G32_NW * 32 * FMW, BN = 32 * FNW, RING = 3;
+    constexpr int BM = G32_NW * 32 * FMW, BN = 32 * FNW;
     const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
     const size_t smem = (size_t)RING * (BM + BN) * 128;
     if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true>), dim3(tiles), dim3(G32_NW * 64), smem, s, p);
@@ -381,6 +391,8 @@ int launch_g32_t(const i2i_igemm_params& p, hipStream_t s) {
         case 52: return launch_g32<T, 1, 5>(p, s);
         case 53: return launch_g32<T, 2, 4>(p, s);
         case 54: return launch_g32<T, 1, 4>(p, s);
+        case 55: return launch_g32<T, 1, 5, 2>(p, s);
+        case 56: return launch_g32<T, 1, 4, 2>(p, s);
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: unknown tile config %d", p.tile);
 }

@@ -332,7 +332,7 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
-    // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..54 = force)
+    // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..56 = force)
     if (p.tile >= 50 && p.tile <= 59 && !i2i::gemm_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (wide GEMM) not applicable", p.tile);
     if (routes_to_gemm_w32(p, dtype)) return i2i::gemm_w32(p, dtype, s);
     // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)

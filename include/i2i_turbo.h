@@ -90,8 +90,9 @@ typedef struct {
     int32_t tile;              /* 0 = auto; else forces a kernel / tile config id (tests / tuning):
                                   1-5 register-staged igemm, 10-19 / 30-39 halo conv3x3, 20-25 LDS-DMA igemm,
                                   40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto; with `subpix` its
-                                  sub-pixel upsampler form), 50-54 wide GEMM (32x32x16 MFMA, gemm_w32.hip; 50 = its own auto,
-                                  51 256x160, 52 128x160, 53 256x128, 54 128x128 workgroup tiles).
+                                  sub-pixel upsampler form), 50-56 wide GEMM (32x32x16 MFMA, gemm_w32.hip; 50 = its own auto,
+                                  51 256x160, 52 128x160, 53 256x128, 54 128x128 workgroup tiles; 55 / 56 = 52 / 54 with a 2-deep
+                                  ring, two workgroups per CU).
                                   `bias` (bias_mode 1) must be 4-byte aligned; the 3x3 conv routes need it 16-byte aligned */
     int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
     void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */

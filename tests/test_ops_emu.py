@@ -446,18 +446,18 @@ def test_w32_conv_second_contraction_plain_form(emu_lib, cfg):
 
 
 # ---------------------------------------------------------------- wide GEMM (gemm_w32.hip, tile ids 51..54)
-@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54, 55, 56])
 def test_gemm_w32_tiles(emu_lib, cfg):
     """nn.Linear / 1x1 conv on 32x32x16 MFMA: ragged row and column tiles, residual + bias + alpha, K of 1 / 2 / 5 stages
     (shorter than, equal to and longer than the ring), two channel-concatenated sources, both 16-bit types."""
-    bn = 160 if cfg in (51, 52) else 128
+    bn = 160 if cfg in (51, 52, 55) else 128
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=320, cout=2 * bn + 40, h=9, w=37, ks=1, pad=0, res=True, alpha=0.7, tile=cfg)    # 5 stages, ragged M and N
     oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cout=bn, h=8, w=16, ks=1, pad=0, tile=cfg)                                   # 1 stage, exact tiles
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=bn, h=5, w=13, ks=1, pad=0, res=True, bias=False, tile=cfg)  # [c0 | c1], source switch at stage 1
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=96, h=7, w=20, ks=1, pad=0, tile=cfg)                                 # 2 stages, one ragged column tile
 
 
-@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54, 55, 56])
 def test_gemm_w32_geglu(emu_lib, cfg):
     oc.check_geglu(emu_lib, "cpu", torch.bfloat16, tile=cfg, cff=320, rows=300, cin=128)       # N = 640 packed columns
     oc.check_geglu(emu_lib, "cpu", torch.float16, tile=cfg, cff=64, rows=70, cin=64)           # N = 128: one (ragged for 160) column tile

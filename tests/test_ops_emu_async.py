@@ -127,14 +127,14 @@ def test_skew_notices_a_forgotten_barrier(emu_lib, monkeypatch):
         oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=448, cout=160, h=9, w=37, ks=1, pad=0, tile=51)
 
 
-@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54, 55, 56])
 @pytest.mark.parametrize("order", [None, "0", "1", "7"])
 def test_gemm_w32_waits_and_barriers(async_lib, cfg, order, monkeypatch):
     """Wide GEMM (gemm_w32.hip): the counted vmcnt of the 3-deep operand ring (window pieces spread over four k16 steps, dummy
     pieces past the last stage) and the one barrier per stage, on the latest-completion memory model with run-ahead wave orders."""
     if order is not None:
         monkeypatch.setenv("I2I_EMU_ORDER", order)
-    bn = 160 if cfg in (51, 52) else 128
+    bn = 160 if cfg in (51, 52, 55) else 128
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=448, cout=bn + 40, h=9, w=37, ks=1, pad=0, res=True, tile=cfg)     # 7 stages: the ring wraps twice
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=bn, h=5, w=13, ks=1, pad=0, tile=cfg)           # 3 stages = the ring, two sources
     oc.check_conv(async_lib, "cpu", torch.float16, n=1, cin=128, cout=bn, h=4, w=16, ks=1, pad=0, tile=cfg)                     # 2 stages: shorter than the ring
