@@ -58,7 +58,8 @@ class AttentionParams(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
                 ("batch", i32), ("heads", i32), ("d", i32), ("tq", i32), ("tk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldvt", i32), ("ldo", i32),
-                ("q_bs", i64), ("k_bs", i64), ("vt_bs", i64), ("o_bs", i64), ("scale", f32), ("causal", i32)]
+                ("q_bs", i64), ("k_bs", i64), ("vt_bs", i64), ("o_bs", i64), ("scale", f32), ("causal", i32),
+                ("ksplit", i32), ("ws", vp)]
 
 
 class EmbedParams(C.Structure):
@@ -179,7 +180,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 5:
+        if L.i2i_abi_version() != 6:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

@@ -402,7 +402,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
 //   * every fragment read feeds one MFMA here (16 queries per wave), so LDS read bandwidth and the matrix pipe are
 //     balanced by construction; the O^T rescale is skipped when no running max moved in the wave (the common case
 //     after the first tiles).
-template <typename T, int D, int QF, int NW>
+// SPLIT (p.ksplit > 1, p.ws): the key tiles are divided among ksplit workgroups per query tile ("flash decoding"): a batch-1
+// forward has 32 query tiles -- 32 of 256 CUs, all on one XCD with the group-per-XCD order -- and 128 serial key tiles each.
+// Split workgroup (b, h, ks) runs tiles ks*per .. and writes its UNNORMALISED O^T (fp32) plus the running (max, sum) of every
+// query to p.ws; attention_combine_kernel merges the ksplit partials.  A (b, h, ks) triple is a "group" of the XCD-aware order,
+// so the splits of one head land on different XCDs and each L2 streams only its share of K / V^T.
+template <typename T, int D, int QF, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(const i2i_attention_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8 && D % 128 == 0, "16-bit types, D a multiple of 128");
@@ -416,14 +421,27 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
     static_assert((BKV + D / 16) % NW == 0, "");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    int qt, h, b;
-    if (!att_group_of_block((p.tq + BQ - 1) / BQ, p.heads, p.batch, qt, h, b)) return;
+    int qt, h, b, ks = 0;
+    if constexpr (!SPLIT) {
+        if (!att_group_of_block((p.tq + BQ - 1) / BQ, p.heads, p.batch, qt, h, b)) return;
+    } else {
+        int hs;
+        if (!att_group_of_block((p.tq + BQ - 1) / BQ, p.heads * p.ksplit, p.batch, qt, hs, b)) return;
+        h = hs / p.ksplit;
+        ks = hs - h * p.ksplit;
+    }
     const int q0 = qt * BQ + wave * (QF * 16);
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
     const char* vp = (const char*)((const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)h * D * p.ldvt);
-    const int ntile = (p.tk + BKV - 1) / BKV;
+    const int ntile_all = (p.tk + BKV - 1) / BKV;
+    int t_begin = 0, ntile = ntile_all;                   // this workgroup's key tiles: t_begin .. ntile - 1
+    if constexpr (SPLIT) {
+        const int per = (ntile_all + p.ksplit - 1) / p.ksplit;
+        t_begin = ks * per;
+        ntile = t_begin + per < ntile_all ? t_begin + per : ntile_all;
+    }
     auto voff = [](int row, int c) __attribute__((always_inline)) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); };
 
     // op pc = q*NW + wave; pc < BKV: K row pc (one key, D/8 chunks = 64 lanes), else 16 V^T rows (4 chunks each).
@@ -484,9 +502,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
     for (int f = 0; f < QF; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
     const float c2 = p.scale * 1.44269504088896341f;
 
-    dma_tile(0, 0);
-    for (int t = 0; t < ntile; ++t) {
-        const int st = t & 1, kv0 = t * BKV;
+    if (t_begin < ntile) dma_tile(t_begin, 0);
+    for (int t = t_begin; t < ntile; ++t) {
+        const int st = (t - t_begin) & 1, kv0 = t * BKV;
         wait_vmcnt<0>();                 // tile t has landed (requested one tile ago)
         lds_barrier();                   // ... for everyone, and everyone is done reading tile t-1
         if (t + 1 < ntile) dma_tile(t + 1, st ^ 1);
@@ -605,6 +623,21 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = 1.0f / l_tot;
         const int qi = q0 + f * 16 + lr;
+        if constexpr (SPLIT) {
+            // partial results: ws = [G][tq][D] fp32 unnormalised O, then [G][tq][2] = (running max in scaled log2 units, sum)
+            const int64_t G = (int64_t)p.batch * p.heads * p.ksplit, gq = (((int64_t)b * p.heads + h) * p.ksplit + ks) * p.tq + qi;
+            if (qi < p.tq) {
+                float* wo = (float*)p.ws + gq * D;
+#pragma unroll
+                for (int i = 0; i < DF; ++i) *(f32x4*)(wo + i * 16 + lq * 4) = oacc[f][i];
+                if (lq == 0) {
+                    float* ml = (float*)p.ws + G * p.tq * D + gq * 2;
+                    ml[0] = m_run[f];
+                    ml[1] = l_tot;
+                }
+            }
+            continue;
+        }
         if (qi < p.tq) {
             T* op = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D;
             typedef T tx4 __attribute__((ext_vector_type(4)));
@@ -619,11 +652,52 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void attention_wide_kernel(c
     }
 }
 
+// Merge of the key-split partials: one wave per query, a lane owns D / 64 = 8 channels.  With m_s the running max of split s
+// (scaled log2 units) and M = max_s m_s:  O = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s.  An empty split has l = 0, O = 0.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attention_combine_kernel(const i2i_attention_params p) {
+    static_assert(D == 512, "8 channels per lane");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nq = (int64_t)p.batch * p.heads * p.tq, q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const int64_t bh = q / p.tq;
+    const int qi = (int)(q - bh * p.tq), b = (int)(bh / p.heads), h = (int)(bh - (int64_t)b * p.heads);
+    const int S = p.ksplit;
+    const float* part = (const float*)p.ws;
+    const float* ml = part + (int64_t)p.batch * p.heads * S * p.tq * D;
+    float M = -1e30f;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, ml[((bh * S + s) * p.tq + qi) * 2]);
+    float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const int64_t gq = (bh * S + s) * p.tq + qi;
+        const float w = exp2_fast(ml[gq * 2] - M);
+        L += w * ml[gq * 2 + 1];
+        const f32x4 v0 = *(const f32x4*)(part + gq * D + lane * 8), v1 = *(const f32x4*)(part + gq * D + lane * 8 + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] += w * v0[r]; acc[4 + r] += w * v1[r]; }
+    }
+    const float inv = 1.0f / L;
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    tx8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(acc[r] * inv);
+    *(tx8*)((T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D + lane * 8) = o;
+}
+
 template <typename T>
 int launch_att_wide(const i2i_attention_params& p, hipStream_t s) {
     constexpr int QF = 1, NW = 8;                  // 8 waves x 16 queries, two waves per SIMD (256 registers each)
-    const dim3 grid(att_grid((p.tq + NW * QF * 16 - 1) / (NW * QF * 16), p.heads, p.batch));
-    hipLaunchKernelGGL((attention_wide_kernel<T, 512, QF, NW>), grid, dim3(NW * 64), (size_t)2 * (32 * 512 * 2 + 512 * 64), s, p);
+    const int nqt = (p.tq + NW * QF * 16 - 1) / (NW * QF * 16);
+    const size_t smem = (size_t)2 * (32 * 512 * 2 + 512 * 64);
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL((attention_wide_kernel<T, 512, QF, NW, true>), dim3(att_grid(nqt, p.heads * p.ksplit, p.batch)), dim3(NW * 64), smem, s, p);
+        int rc = i2i::check_launch("attention_wide(split)");
+        if (rc != I2I_OK) return rc;
+        const int64_t nq = (int64_t)p.batch * p.heads * p.tq;
+        hipLaunchKernelGGL((attention_combine_kernel<T, 512>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p);
+        return i2i::check_launch("attention_combine");
+    }
+    hipLaunchKernelGGL((attention_wide_kernel<T, 512, QF, NW>), dim3(att_grid(nqt, p.heads, p.batch)), dim3(NW * 64), smem, s, p);
     return i2i::check_launch("attention_wide");
 }
 
@@ -659,6 +733,8 @@ extern "C" int i2i_attention(const i2i_attention_params* p, int dtype, void* str
     // register-staged kernel
     const bool dma_ok = (p->ldo % 4 == 0) && (p->o_bs % 4 == 0) && (((uintptr_t)p->o & 7) == 0) && (((uintptr_t)p->k | (uintptr_t)p->vt) & 15) == 0 &&
                         (p->ldk % 8 == 0) && (p->k_bs % 8 == 0) && (p->vt_bs % 8 == 0);
+    if (p->ksplit > 1 && (p->d != 512 || dtype == I2I_F32 || !p->ws || (((uintptr_t)p->ws) & 15) || p->ldo % 8 || p->o_bs % 8 || (((uintptr_t)p->o) & 15)))
+        return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: ksplit is implemented by the d = 512 16-bit kernel and needs a 16-byte aligned workspace and output rows");
     if (p->d == 512) {
         if (!dma_ok || p->causal || p->ldq % 8 || (((uintptr_t)p->q) & 15) || p->q_bs % 8 || p->tk < 8 ||
             (int64_t)p->tk * p->ldk * 2 >= (int64_t(1) << 32) || (int64_t)p->d * p->heads * p->ldvt * 2 >= (int64_t(1) << 32))

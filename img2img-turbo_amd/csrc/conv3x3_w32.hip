@@ -82,6 +82,7 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }    
 #endif
 
 constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
+constexpr int SPX_ROW_CHUNKS = W32_TW / 4;              // row layout of the epilogue: a lane owns chunk c16 of pixels p4, p4 + 4, ...: 8 per 32-pixel row
 // bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
 constexpr int w32_plane_px(int halo_px) { return ((halo_px * 32 + 127) / 128) * 128 + 32; }
 constexpr int w32_plane(int th, bool subpix = false) { return w32_plane_px(subpix ? (th + 1) * (W32_TW + 1) : (th + 2) * (W32_TW + 2)); }
@@ -361,15 +362,35 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto none = []() __attribute__((always_inline)) {};
 
     constexpr int DMA_OPS = BPW;
-    auto step = [&](int slab, auto tapc) __attribute__((always_inline)) {
+    // RES: the LAST slab has no next halo to stage; its hidden-load slots (same count per window, so every counted wait stays
+    // exact) fetch the first NPRE tile rows of the RESIDUAL in the epilogue's row layout instead of dummy halo chunks: the
+    // epilogue finds them in rh[] with their HBM latency already paid under the slab's MFMAs (it used to expose one load
+    // latency per tile row at one row of look-ahead: conv2 of a 128-channel resnet ran 0.12 - 0.19 ms behind its conv1).
+    constexpr int RCH = SPX_ROW_CHUNKS;                   // 16-byte chunks of one 32-pixel tile row per lane (row layout)
+#ifndef W32_NPRE_MAX
+#define W32_NPRE_MAX 4                                    // (0: the A/B baseline -- every residual row is fetched by the epilogue)
+#endif
+    constexpr int NPRE0 = (RES && !SUBPIX) ? (HPT / RCH < FM ? HPT / RCH : FM) : 0;
+    constexpr int NPRE = NPRE0 < W32_NPRE_MAX ? NPRE0 : W32_NPRE_MAX;
+    unsigned rp_lane = 0u, rp_okk = 0u;                   // per lane: byte offset of (pixel p4, chunk c16) in a residual row; bit k: pixel k*4 + p4 and the chunk are inside
+    auto res_prefetch = [&](int j) __attribute__((always_inline)) {      // j = i * RCH + k: chunk k of tile row i
+        const int i = j / RCH, k = j - i * RCH;
+        const int oy = ty0 + wm * FM + i;
+        const bool rowok = oy < p.ho;
+        const char* rbase = (const char*)((const T*)p.res + (((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0) * p.ldr);      // uniform
+        const bool ok = rowok && ((rp_okk >> k) & 1u);
+        gload16_uncounted(rh[j], rbase, ok ? rp_lane + (unsigned)(k * 4 * p.ldr) * (unsigned)sizeof(T) : 0u);
+    };
+    auto step = [&](int slab, auto tapc, auto lastc) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value;
+        constexpr bool LAST = decltype(lastc)::value && NPRE > 0;
         // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
         // (SUBPIX: four taps per slab and no transform -- the chunks are fenced and their padding zeroed at the store)
         auto xf_q = [&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
-            if constexpr (!SUBPIX && tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
+            if constexpr (!SUBPIX && !LAST && tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
         };
-        auto has_q = [&](int q) constexpr { return !SUBPIX && tap >= 3 && tap - 3 + q * LW < HPT; };
+        auto has_q = [&](int q) constexpr { return !SUBPIX && !LAST && tap >= 3 && tap - 3 + q * LW < HPT; };
         kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
         kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
         kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
@@ -389,13 +410,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             const int hs = slab + 1 < nslab ? slab + 1 : slab;
             if constexpr (tap < LW) {
 #pragma unroll
-                for (int j = tap; j < HPT; j += LW) halo_load(hs, j, true);
+                for (int j = tap; j < HPT; j += LW) {
+                    if (LAST && j < NPRE * RCH) res_prefetch(j);
+                    else halo_load(hs, j, true);
+                }
             }
         }
-        constexpr int NST = (tap == NTAPS - 1) ? HPT : 0;
+        constexpr int NST = (tap == NTAPS - 1 && !LAST) ? HPT : 0;
         kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
               [&]() __attribute__((always_inline)) {
-                  if constexpr (tap == NTAPS - 1) {
+                  if constexpr (tap == NTAPS - 1 && !LAST) {
 #pragma unroll
                       for (int j = 0; j < HPT; ++j) {
                           if constexpr (SUBPIX) { reg_fence(rh[j]); halo_xform(j); }
@@ -419,13 +443,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #pragma unroll
     for (int j = 0; j < FN; ++j) wf[0][j] = wread(0, j, 0);
 
-    for (int slab = 0; slab < nslab; ++slab) {
+    // (with a residual the last slab is a second copy of the nine steps: no next halo, residual rows in its load slots)
+    const int nslab_main = NPRE > 0 ? nslab - 1 : nslab;
+    for (int slab = 0; slab < nslab_main; ++slab) {
         load_ssr(slab + 1 < nslab ? slab + 1 : slab);     // constants of the slab whose halo is transformed during this one (from tap 3 on)
         __builtin_amdgcn_sched_barrier(0);                // (its ds_reads must not take the fragment reads' slots in the pinned schedule)
-        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, tc); });
+        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(slab, tc, icw<0>{}); });
         lds_barrier();                                    // the next slab's halo (stored after P_8) is complete
 #pragma unroll
         for (int i = 0; i < FM; ++i) xf[0][i] = xread(0, i, 0);
+        W32_TR(5);
+    }
+    if constexpr (NPRE > 0) {
+        {
+            int pl = lane;
+            opaque(pl);                                   // (derived here, not hoisted across the main loop)
+            const int c16 = pl & 15, p4 = pl >> 4;
+            const int nrb = n0 + wn * WTN + c16 * 8;
+            rp_lane = (unsigned)(p4 * p.ldr + nrb) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < RCH; ++k) rp_okk |= (nrb < p.N && tx0 + k * 4 + p4 < p.wo) ? (1u << k) : 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_w<NTAPS>([&](auto tc) __attribute__((always_inline)) { step(nslab - 1, tc, icw<1>{}); });
         W32_TR(5);
     }
     // the tail windows issued DMA and (unused) halo loads: everything must have landed before LDS / registers are reused
@@ -434,6 +474,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     for (int j = 0; j < HPT; ++j) reg_fence(rh[j]);
 
     lds_barrier();                                       // every wave is done with the halo planes / the ring: the staging blocks reuse them
+    if constexpr (NPRE > 0) {
+        // residual rows fetched by the last slab -> their staging blocks, in the epilogue's row layout (pixel k*4 + p4, chunk c16 at
+        // p4*256 + ((c16 ^ p4) << 4) + k*1024, bits 6-7 ^ (k*4 & 12)); rh[] is dead from here on
+        int sl = lane;
+        opaque(sl);
+        const int c16 = sl & 15, p4 = sl >> 4;
+        char* const blk = i2i_smem + wave * ((NPRE + 1) * W32_TW * 256);
+        const int rl = p4 * 256 + ((c16 ^ p4) << 4);
+#pragma unroll
+        for (int r = 0; r < NPRE; ++r)
+#pragma unroll
+            for (int k = 0; k < RCH; ++k) *(chunk_t*)(blk + r * (W32_TW * 256) + ((rl + k * 1024) ^ (((k * 4) & 12) << 4))) = rh[r * RCH + k];
+        wave_sync();
+    }
 
     // ---- second contraction (p.k2_a): acc += k2_a[pixel][0..k2_c) . k2_b[n][0..k2_c)^T with the pixels taken at the OUTPUT
     // positions of this tile (sub-pixel form: of this parity).  Two users: the decoder's `sample = sample + skip_conv_i(skip *
@@ -511,7 +565,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     // quad).  The residual is loaded in the row layout (full lines), staged through the same image and added in fp32
     // before the one rounding.
     constexpr int SPX = 32, NRND = 1;                    // a whole 32-pixel tile row per staging round
-    static_assert(WTN == 128 && 4 * PLANE >= NW * SPX * 256, "");
+    static_assert(WTN == 128 && BS0 + RING * BN * 128 >= NW * (NPRE + 1) * SPX * 256, "the staging blocks fit in front of the GroupNorm constants / the bias");
     typedef T tx4 __attribute__((ext_vector_type(4)));
     typedef T tx2 __attribute__((ext_vector_type(2)));
     const T* __restrict__ res = (const T*)p.res;
@@ -524,7 +578,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         opaque(elane);
         const int l31 = elane & 31, lh = elane >> 5;
         const int c16 = elane & 15, p4 = elane >> 4;          // row-layout role: chunk c16 of pixels p4, p4+4, ...
-        char* const stg = i2i_smem + wave * (SPX * 256);          // the halo planes are dead: 8 KiB per wave from the LDS base
+        // the halo planes / the ring are dead: NPRE + 1 staging blocks of 8 KiB per wave from the LDS base (block r < NPRE already
+        // holds residual row r, stored right after the K loop; block NPRE serves the other rows)
+        char* const stg0 = i2i_smem + wave * ((NPRE + 1) * SPX * 256);
         const int nrb = n0 + wn * WTN + c16 * 8;              // first channel of the row-layout chunk
         const bool nok = FULL || nrb < p.N;
         // byte offsets of this lane's row-layout chunk inside the staging image (pixel k*4 + p4) and of its pieces
@@ -543,25 +599,37 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #define W32_RDEPTH (BN == 128 ? 1 : 2)
 #endif
         constexpr bool RAHEAD = W32_RDEPTH > 0;              // (0: fetch each row at its use -- the A/B baseline)
-        constexpr int RDEPTH = !RAHEAD ? 1 : (FM < W32_RDEPTH ? FM : W32_RDEPTH);
+        // (rows the last slab fetched count towards the look-ahead: more rows in registers than this and hipcc, which parks whole
+        // rows of accumulators in VGPRs, spills the residual right after loading it)
+        constexpr int RDEPTH0 = !RAHEAD ? 1 : (FM < W32_RDEPTH ? FM : W32_RDEPTH);
+        constexpr int RDEPTH = RDEPTH0 - NPRE > 1 ? RDEPTH0 - NPRE : 1;
+        // Rows 0 .. NPRE-1 of the residual were fetched by the last slab and already sit in their own staging blocks (below);
+        // the other rows go through rr[]: row NPRE + d is requested up front, row i + RDEPTH as soon as row i has been staged.
+        static_assert(SPX / 4 == SPX_ROW_CHUNKS, "");
         chunk_t rr[RES ? RDEPTH : 1][SPX / 4];
         auto res_load = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (RES && i < FM) {
+            if constexpr (RES && i >= NPRE && i < FM) {
                 const int oy = ty0 + wm * FM + i;
                 const bool rowok = FULL || oy < p.ho;
                 const T* const rbase = res + (((int64_t)img * p.ho + (rowok ? oy : 0)) * p.wo + tx0) * p.ldr;      // uniform
 #pragma unroll
                 for (int k = 0; k < SPX / 4; ++k) {
                     const bool ok = FULL || (rowok && nok && tx0 + k * 4 + p4 < p.wo);
-                    rr[i % RDEPTH][k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(k * 4 * p.ldr) + r_lane : 0u));
+                    rr[(i - NPRE) % RDEPTH][k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(k * 4 * p.ldr) + r_lane : 0u));
                 }
             }
         };
-        if constexpr (RAHEAD) static_for_w<RDEPTH>([&](auto ic) __attribute__((always_inline)) { res_load(ic); });
+        // (row j >= NPRE is requested RDEPTH rows ahead of its use: up front when j < RDEPTH, at the start of row j - RDEPTH when that
+        // row came staged from the last slab, right after row j - RDEPTH has been staged otherwise)
+        if constexpr (RAHEAD) static_for_w<RDEPTH>([&](auto ic) __attribute__((always_inline)) { res_load(ic); });      // (rows < NPRE: no-op)
         static_for_w<FM>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
+            char* const stg = stg0 + (i < NPRE ? i : NPRE) * (SPX * 256);
             __builtin_amdgcn_sched_barrier(0);                // one tile row at a time (register budget)
+            // (16 x 32 x 128 tiles: at the row's start; the 8 x 32 x 256 tile requests it between (b) and (c) -- at the start of its
+            // first row hipcc spills the freshly loaded row around the accumulator copies)
+            if constexpr (RES && RAHEAD && i < NPRE && i + RDEPTH >= NPRE && BN == 128) res_load(icw<i + RDEPTH>{});
             const int sy = ty0 + wm * FM + i;                 // row in the plane the tiles walk
             const bool rowok = FULL || sy < pl_h;
             const int oy = SUBPIX ? 2 * sy + pa : sy;
@@ -571,10 +639,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             opaque(blane);
 #pragma unroll
             for (int rd = 0; rd < NRND; ++rd) {
-                if constexpr (RES) {                           // (a) residual of the row's pixels, row layout -> stage
+                if constexpr (RES && i >= NPRE) {              // (a) residual of the row's pixels, row layout -> stage
                     if constexpr (!RAHEAD) res_load(icw<i>{});
 #pragma unroll
-                    for (int k = 0; k < SPX / 4; ++k) *(chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4))) = rr[i % RDEPTH][k];
+                    for (int k = 0; k < SPX / 4; ++k) *(chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4))) = rr[(i - NPRE) % RDEPTH][k];
                     wave_sync();
                     if constexpr (RAHEAD) res_load(icw<i + RDEPTH>{});      // the registers are free again: row i + RDEPTH
                 }
@@ -606,6 +674,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 }
                 wave_sync();
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RES && RAHEAD && i < NPRE && i + RDEPTH >= NPRE && BN != 128) res_load(icw<i + RDEPTH>{});
                 // (c) whole rows back: full-line stores + statistics of what is stored
                 T* const orow = obase + o_lane;
 #pragma unroll
@@ -632,7 +701,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             gq0 += __shfl_xor(gq0, 16); gq0 += __shfl_xor(gq0, 32);
             gs1 += __shfl_xor(gs1, 16); gs1 += __shfl_xor(gs1, 32);
             gq1 += __shfl_xor(gq1, 16); gq1 += __shfl_xor(gq1, 32);
-            float* st = (float*)stg;                         // [32 quads][2]
+            float* st = (float*)stg0;                        // [32 quads][2]
             if (p4 == 0) {
                 st[(c16 * 2 + 0) * 2 + 0] = gs0; st[(c16 * 2 + 0) * 2 + 1] = gq0;
                 st[(c16 * 2 + 1) * 2 + 0] = gs1; st[(c16 * 2 + 1) * 2 + 1] = gq1;
@@ -646,7 +715,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                 const int c0w = etid * cpg, wnn = c0w / WTN, q0 = (c0w - wnn * WTN) >> 2, nq = cpg >> 2;
                 float S = 0.f, Q = 0.f;
                 for (int wmm = 0; wmm < WM; ++wmm) {
-                    const float* sw = (const float*)(i2i_smem + (wmm * WN + wnn) * (SPX * 256));
+                    const float* sw = (const float*)(i2i_smem + (wmm * WN + wnn) * ((NPRE + 1) * SPX * 256));
                     for (int q = q0; q < q0 + nq; ++q) { S += sw[q * 2]; Q += sw[q * 2 + 1]; }
                 }
                 const int tile_in_img = ((ty0 / TH) * tiles_x + tx0 / TW) * NPAR + pa * 2 + pb;      // (one slot per tile and parity)

@@ -50,11 +50,27 @@ __device__ __forceinline__ void sopaque(unsigned& x) { asm volatile("" : "+v"(x)
 
 __device__ __attribute__((aligned(16))) uint32_t g32_zero16[4] = {0u, 0u, 0u, 0u};   // DMA source of the dummy pieces
 
+// c + a.x*b.x + a.y*b.y in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16): two stored channels per instruction for the statistics
+typedef __bf16 g32_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 g32_f16x2 __attribute__((ext_vector_type(2)));
+#ifdef I2I_EMU
+__device__ __forceinline__ float g32_dot2(g32_bf16x2 a, g32_bf16x2 b, float c) { return fmaf((float)a[1], (float)b[1], fmaf((float)a[0], (float)b[0], c)); }
+__device__ __forceinline__ float g32_dot2(g32_f16x2 a, g32_f16x2 b, float c) { return fmaf((float)a[1], (float)b[1], fmaf((float)a[0], (float)b[0], c)); }
+#else
+__device__ __forceinline__ float g32_dot2(g32_bf16x2 a, g32_bf16x2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+__device__ __forceinline__ float g32_dot2(g32_f16x2 a, g32_f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+#endif
+
 constexpr int G32_NW = 4, G32_BK = 64, G32_KQ = 4;       // waves per workgroup (stacked along M), K per stage, k16 steps per stage
 
 // FMW / FNW: 32-row / 32-column fragments per wave.  Workgroup tile = (4 * 32 * FMW) rows x (32 * FNW) columns.
-template <typename T, int FMW, int FNW, int RING, bool GEGLU>
+// GATHER: the A operand is the im2col view of a 3x3 convolution (stride 1 or 2, zero padding 0 or 1 incl. the VAE downsamplers'
+// F.pad(0,1,0,1)) over ONE NHWC source with cin % 64 == 0: stage s = 64 channels of tap s*64 / cin, the tap's pixel offset is
+// a scalar added to the per-lane source offset of every A piece, taps outside the plane read a 16-byte zero block.
+// STATS: the epilogue also emits the GroupNorm partial sums of the STORED output (p.gn_part), one slot per (row tile, group).
+template <typename T, int FMW, int FNW, int RING, bool GEGLU, bool GATHER = false, bool STATS = false>
 __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igemm_params p) {
+    static_assert(!(GEGLU && (GATHER || STATS)), "");
     constexpr int NW = G32_NW, BK = G32_BK, KQ = G32_KQ;
     constexpr int WTM = 32 * FMW, BM = NW * WTM, BN = 32 * FNW;
     constexpr int STAGE = (BM + BN) * 128;
@@ -96,11 +112,27 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const int r8 = lane >> 3;
     const unsigned sch16 = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (r8 >> 1))) << 4);      // byte offset of the source chunk in its row
     unsigned a_row[QA], a_voff[QA], b_voff[QB];
+    unsigned a_ok[GATHER ? QA : 1];                       // GATHER: bit t = tap t of this piece's row lies inside the plane
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-        const int m = m0 + (wave + q * NW) * 8 + r8;
-        a_row[q] = (unsigned)(m < p.M ? m : p.M - 1);     // clamped rows feed accumulator rows that are never stored
-        a_voff[q] = a_row[q] * ((unsigned)p.lda0 * 2u) + sch16;
+        int m = m0 + (wave + q * NW) * 8 + r8;
+        m = m < p.M ? m : p.M - 1;                        // clamped rows feed accumulator rows that are never stored
+        a_row[q] = (unsigned)m;
+        if constexpr (!GATHER) {
+            a_voff[q] = a_row[q] * ((unsigned)p.lda0 * 2u) + sch16;
+        } else {
+            const int hw = p.ho * p.wo;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / p.wo, ox = rem - oy * p.wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            // byte offset of tap (0,0): may be "negative" (wraps; such a tap is masked, the valid ones wrap back)
+            a_voff[q] = (unsigned)((img * p.hin + iy0) * p.win + ix0) * ((unsigned)p.lda0 * 2u) + sch16;
+            unsigned ok = 0u;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(iy0 + t / 3) < (unsigned)p.hin && (unsigned)(ix0 + t % 3) < (unsigned)p.win) ok |= 1u << t;
+            a_ok[q] = ok;
+        }
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
@@ -120,11 +152,27 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const char* w_bbase = zero;
     unsigned w_msk = 0u;
     char* w_dst = i2i_smem;
+    // GATHER: (tap, channel offset) of the NEXT window to open -- windows open in stage order, so the decode is a running
+    // counter in scalar registers -- and of the open one: tap index (bit of a_ok) and byte offset of (tap pixel, channels)
+    int g_tap = 0, g_ky = 0, g_kx = 0, g_ci = 0;
+    unsigned w_tap = 0u, w_aoff = 0u;
     auto open_window = [&](int s, int slot) __attribute__((always_inline)) {      // s < 0: dummy window
         const bool on = s >= 0;
-        const int sa = s >= s_sw ? s - s_sw : s;
-        const char* ab = (s >= s_sw ? a1 : a0) + (size_t)(sa < 0 ? 0 : sa) * (BK * 2);
-        w_abase = on ? ab : zero;
+        if constexpr (!GATHER) {
+            const int sa = s >= s_sw ? s - s_sw : s;
+            const char* ab = (s >= s_sw ? a1 : a0) + (size_t)(sa < 0 ? 0 : sa) * (BK * 2);
+            w_abase = on ? ab : zero;
+        } else {
+            w_tap = (unsigned)g_tap;
+            w_aoff = (unsigned)((g_ky * p.win + g_kx) * p.lda0 + g_ci) * 2u;
+            g_ci += BK;                                    // (selects, not branches: the K loop stays one basic block per half)
+            const int wrap = g_ci == p.c0 ? 1 : 0;
+            g_ci = wrap ? 0 : g_ci;
+            g_tap += wrap; g_kx += wrap;
+            const int wrap3 = g_kx == 3 ? 1 : 0;
+            g_kx = wrap3 ? 0 : g_kx;
+            g_ky += wrap3;
+        }
         w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s) * (BK * 2) : zero;
         w_msk = on ? 0xffffffffu : 0u;
         w_dst = i2i_smem + slot * STAGE;
@@ -132,8 +180,14 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     };
     auto dma_piece = [&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value;
-        if constexpr (q < QA) glds16_sv(w_abase, a_voff[q] & w_msk, w_dst + (wave + q * NW) * 1024);
-        else glds16_sv(w_bbase, b_voff[q - QA] & w_msk, w_dst + (PA + wave + (q - QA) * NW) * 1024);
+        if constexpr (q < QA) {
+            if constexpr (!GATHER) {
+                glds16_sv(w_abase, a_voff[q] & w_msk, w_dst + (wave + q * NW) * 1024);
+            } else {
+                const bool ok = ((a_ok[q] >> w_tap) & w_msk & 1u) != 0u;      // dummy windows (w_msk == 0) and taps past 8: zeros
+                glds16(ok ? a0 + (a_voff[q] + w_aoff) : zero, w_dst + (wave + q * NW) * 1024);
+            }
+        } else glds16_sv(w_bbase, b_voff[q - QA] & w_msk, w_dst + (PA + wave + (q - QA) * NW) * 1024);
     };
     auto a_voff_for = [&](bool second) __attribute__((always_inline)) {
         const unsigned ldb2 = (unsigned)(second ? p.lda1 : p.lda0) * 2u;
@@ -242,6 +296,14 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const T* __restrict__ res = (const T*)p.res;
     T* __restrict__ out = (T*)p.c;
     if constexpr (!GEGLU) {
+        // STATS: (sum, sum of squares) of the lane's stored values per 4-channel quad: index ((j*2 + pr)*2 + h)*2 + {0, 1}
+        constexpr int NV = STATS ? FNW * 8 : 1;
+        typedef T tx2 __attribute__((ext_vector_type(2)));
+        float gacc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) gacc[v] = 0.f;
+        tx2 ones;
+        ones[0] = (T)1.0f; ones[1] = (T)1.0f;
 #pragma unroll
         for (int j = 0; j < FNW; ++j) {
 #pragma unroll
@@ -281,6 +343,55 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
                     *(tx8*)(out + (int64_t)m * p.ldc + n) = o;
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            tx2 d0, d1;
+                            d0[0] = o[4 * h]; d0[1] = o[4 * h + 1]; d1[0] = o[4 * h + 2]; d1[1] = o[4 * h + 3];
+                            const int vi = ((j * 2 + pr) * 2 + h) * 2;
+                            gacc[vi] = g32_dot2(d0, ones, gacc[vi]);         gacc[vi] = g32_dot2(d1, ones, gacc[vi]);
+                            gacc[vi + 1] = g32_dot2(d0, d0, gacc[vi + 1]);   gacc[vi + 1] = g32_dot2(d1, d1, gacc[vi + 1]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- GroupNorm partial sums of the stored tile (the next layer's norm): lane (l31, lh) holds NV sums over ITS row(s);
+        // rows -> wave through an LDS transpose (lane t adds value t % 32 of the 32 lanes of half t / 32: fixed order), waves ->
+        // workgroup -> one slot per (image, row tile, group).  The operand ring is dead: every wave's DMA has landed (the
+        // wait above) and the barrier below says every wave is done reading it.
+        if constexpr (STATS) {
+            static_assert(!STATS || NV == 32, "one value per lane and half: FNW == 4");
+            if (p.gn_part) {
+                constexpr int LST = NV + 4;                   // lane stride in floats: 16-byte writes of 16 lanes hit 16 distinct bank quads
+                float* st = (float*)i2i_smem;                 // [NW][64][LST]
+                float* st2 = st + NW * 64 * LST;              // [NW][32 quads][2]
+                lds_barrier();
+#pragma unroll
+                for (int v = 0; v < NV; v += 4)
+                    *(f32x4*)(st + (wave * 64 + lane) * LST + v) = f32x4{gacc[v], gacc[v + 1], gacc[v + 2], gacc[v + 3]};
+                lds_barrier();
+                {
+                    const int half = lane >> 5, v = lane & 31;
+                    float tot = 0.f;
+                    for (int l = 0; l < 32; ++l) tot += st[(wave * 64 + half * 32 + l) * LST + v];
+                    const int jpr = v >> 2, h = (v >> 1) & 1, sq = v & 1;        // v = ((j*2 + pr)*2 + h)*2 + sq
+                    const int quad = jpr * 4 + half * 2 + h;                      // column quad of the tile: j*8 + pr*4 + lh*2 + h
+                    st2[(wave * 32 + quad) * 2 + sq] = tot;
+                }
+                lds_barrier();
+                const int groups = p.gn_part_groups, cpg = p.N / groups, ng_tile = BN / cpg;
+                const int g = n0 / cpg + tid;
+                if (tid < ng_tile && g < groups) {
+                    const int q0 = (tid * cpg) >> 2, nq = cpg >> 2;
+                    float S = 0.f, Q = 0.f;
+                    for (int w = 0; w < NW; ++w)
+                        for (int q = q0; q < q0 + nq; ++q) { S += st2[(w * 32 + q) * 2]; Q += st2[(w * 32 + q) * 2 + 1]; }
+                    const int hw = p.ho * p.wo, parts = hw / BM;
+                    const int img = m0 / hw, part = (m0 - img * hw) / BM;
+                    float* o2 = p.gn_part + (((int64_t)img * parts + part) * groups + g) * 2;
+                    o2[0] = S;
+                    o2[1] = Q;
                 }
             }
         }
@@ -379,8 +490,20 @@ int launch_g32(const i2i_igemm_params& p, hipStream_t s) {
     constexpr int BM = G32_NW * 32 * FMW, BN = 32 * FNW;
     const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
     const size_t smem = (size_t)RING * (BM + BN) * 128;
-    if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true>), dim3(tiles), dim3(G32_NW * 64), smem, s, p);
-    else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false>), dim3(tiles), dim3(G32_NW * 64), smem, s, p);
+    const dim3 g(tiles), b(G32_NW * 64);
+    const bool gather = p.ks == 3, stats = p.gn_part != nullptr;
+    // (the gather and the statistics epilogue exist for the 3-deep ring only, the statistics for 128-column tiles only:
+    // gemm_w32_eligible / gemm_w32_gn_parts admit nothing else)
+    if constexpr (RING == 3) {
+        if constexpr (FNW == 4) {
+            if (gather && stats) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, true, true>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<conv,stats>"); }
+            if (stats) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, false, true>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<stats>"); }
+        }
+        if (gather) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, true, false>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<conv>"); }
+    }
+    if (gather || stats) return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: this tile configuration has no 3x3 gather / statistics epilogue");
+    if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true>), g, b, smem, s, p);
+    else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false>), g, b, smem, s, p);
     return i2i::check_launch("gemm_w32");
 }
 
@@ -400,33 +523,64 @@ int launch_g32_t(const i2i_igemm_params& p, hipStream_t s) {
 }  // namespace
 
 namespace i2i {
-// What the wide GEMM takes: a plain 16-bit contraction (1x1, stride 1, no gather, one z), K and the first source in whole
-// 64-wide stages, 16-byte rows everywhere, per-column bias or none, optional residual / GEGLU; offsets fit 32 bits.
+// GroupNorm partial-sum slots per image the wide GEMM writes for this op (0 = it cannot): the 128-column tiles (53 / 54), row
+// tiles that do not straddle images, channels-per-group a multiple of 4 that divides the 128 columns of a tile.
+static int g32_gn_parts(const i2i_igemm_params& p, int groups) {
+    if (groups < 1 || p.N % groups || p.geglu) return 0;
+    const int cfg = g32_cfg(p);
+    if (cfg != 53 && cfg != 54) return 0;
+    const int bm = g32_geometry(cfg).bm, cpg = p.N / groups, hw = p.ho * p.wo;
+    if (cpg % 4 || 128 % cpg || hw % bm) return 0;
+    return hw / bm;
+}
+// What the wide GEMM takes: a 16-bit contraction with one z -- a plain one (1x1, stride 1, up to two channel-concatenated
+// sources) or the im2col view of a 3x3 convolution (stride 1 / 2, padding 0 / 1, one source, no upsample) -- K and the first
+// source in whole 64-wide stages, 16-byte rows everywhere, per-column bias or none, optional residual / GEGLU (plain only) /
+// GroupNorm partial sums of the output (g32_gn_parts); offsets fit 32 bits.
 bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
-    if (p.ks != 1 || p.stride != 1 || p.pad != 0 || p.ups != 0 || p.up_h || p.up_w || p.subpix || p.k2_a) return false;
-    if (p.zcount > 1 || p.splitk > 1 || p.gn_ss || p.gn_part || p.act || p.act_out || p.out_f32 || p.bias_mode == 2) return false;
+    if (p.ks != 1 && p.ks != 3) return false;
+    const bool gather = p.ks == 3;
+    if (!gather && (p.stride != 1 || p.pad != 0)) return false;
+    if (gather && (p.stride < 1 || p.stride > 2 || p.pad < 0 || p.pad > 1 || p.c1 || p.a1 || p.geglu || p.tile == 55 || p.tile == 56)) return false;
+    if (p.ups != 0 || p.up_h || p.up_w || p.subpix || p.k2_a) return false;
+    if (p.zcount > 1 || p.splitk > 1 || p.gn_ss || p.act || p.act_out || p.out_f32 || p.bias_mode == 2) return false;
     const int cin = p.c0 + p.c1;
-    if (p.K != cin || p.K % G32_BK || p.K < G32_BK || (p.c1 && p.c0 % G32_BK)) return false;
+    if (p.K != p.ks * p.ks * cin || cin % G32_BK || cin < G32_BK || (p.c1 && p.c0 % G32_BK)) return false;
     if (p.lda0 % 8 || (p.a1 && p.lda1 % 8) || p.ldb % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b | (uintptr_t)p.c | (uintptr_t)p.res) & 15) return false;
     if (p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return false;
     if (p.M < 1 || p.N < 32 || p.N % 8) return false;
     if (p.geglu && (p.N % 32 || p.bias_mode == 2)) return false;
-    const uint64_t a_bytes = (uint64_t)p.M * (uint64_t)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 2u, b_bytes = (uint64_t)p.N * p.ldb * 2u;
+    if (p.gn_part && g32_gn_parts(p, p.gn_part_groups) == 0) return false;
+    const uint64_t a_rows = gather ? (uint64_t)p.nimg * p.hin * p.win : (uint64_t)p.M;
+    const uint64_t a_bytes = a_rows * (uint64_t)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 2u, b_bytes = (uint64_t)p.N * p.ldb * 2u;
     if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
     return true;
+}
+int gemm_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
+    i2i_igemm_params q = p;
+    q.gn_part = nullptr;                                   // (the query comes before the planner attaches the slab)
+    return gemm_w32_eligible(q, dtype) ? g32_gn_parts(q, groups) : 0;
 }
 // tile == 0 routing (measured per shape against the LDS-DMA igemm, same box: profiles/r4b_bench_ops_gemm.log): the UNet's
 // projections -- widths that are multiples of 160, K of at least five stages -- with at least half a round of workgroups
 // win by 1.2 - 2x (1280 -> 10240 @ 2048 rows: 0.132 -> 0.065 ms); the VAE's 1x1 convolutions (K = 128 .. 512 over 0.5 - 2 M
 // rows: HBM-bound streams of short tiles) are 10 - 40 % FASTER on the LDS-DMA igemm's persistent tile stream and stay there.
-// I2I_GEMM_W32=0 sends everything back to the LDS-DMA igemm, =2 takes every eligible op (A/B and test hook, read per launch).
+// 3x3 convolutions: the stride-2 downsamplers that fill the chip (the VAE encoder's three: K = 1152 .. 4608 over 32 K - 512 K
+// rows); stride-1 3x3 convolutions belong to the halo kernels, the small UNet planes to the split-K LDS-DMA igemm.
+// I2I_GEMM_W32=0 sends everything back to the LDS-DMA igemm, =2 takes every eligible op; I2I_GEMM_W32_CONV=0 keeps the 3x3
+// convolutions off it (A/B and test hooks, read per launch).
 bool gemm_w32_auto(const i2i_igemm_params& p, int dtype) {
     const char* e = getenv("I2I_GEMM_W32");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0 || !gemm_w32_eligible(p, dtype)) return false;
     if (mode == 2) return true;
+    if (p.ks == 3) {
+        const char* ec = getenv("I2I_GEMM_W32_CONV");
+        if ((ec && atoi(ec) == 0) || p.stride != 2 || (p.N % 128 && p.N % 160)) return false;
+        return g32_tiles(p, g32_cfg(p)) >= 256;
+    }
     if (p.N % 160 || p.K < 5 * G32_BK) return false;
     return g32_tiles(p, g32_cfg(p)) >= 128;
 }

@@ -32,6 +32,7 @@ bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype);      // gemm_dma.
 int igemm_dma(const i2i_igemm_params& p, int dtype, hipStream_t s);
 bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype);       // gemm_w32.hip
 bool gemm_w32_auto(const i2i_igemm_params& p, int dtype);           // tile == 0: does the wide GEMM take this op?
+int gemm_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
 
@@ -356,7 +357,7 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32_gn_parts(p, dtype, groups);
     const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
-    if (routes_to_gemm_w32(p, dtype)) return 0;            // the wide GEMM has no statistics epilogue (a planner may force tile 20 instead)
+    if (routes_to_gemm_w32(p, dtype)) return i2i::gemm_w32_gn_parts(p, dtype, groups);      // (0 for the 160-column tiles: a planner may force tile 20 instead)
     if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
     return 0;
 }

@@ -114,14 +114,15 @@ def softmax(s, pout, *, rows, cols, lds, ldp, scale):
     return K.OP_SOFTMAX, p
 
 
-def attention(q, k, vt, o, *, batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, causal=0):
+def attention(q, k, vt, o, *, batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, causal=0, ksplit=0, ws=None):
     p = K.AttentionParams()
+    p.ksplit, p.ws = ksplit, ptr(ws)
     p.q, p.k, p.vt, p.o = ptr(q), ptr(k), ptr(vt), ptr(o)
     p.batch, p.heads, p.d, p.tq, p.tk = batch, heads, d, tq, tk
     p.ldq, p.ldk, p.ldvt, p.ldo = ldq, ldk, ldvt, ldo
     p.q_bs, p.k_bs, p.vt_bs, p.o_bs, p.scale = q_bs, k_bs, vt_bs, o_bs, scale
     p.causal = causal
-    return K.OP_ATTENTION, _keep(p, q, k, vt, o)
+    return K.OP_ATTENTION, _keep(p, q, k, vt, o, ws)
 
 
 def embed(ids, tok, pos, y, *, rows, T, c):

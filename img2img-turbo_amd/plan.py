@@ -112,6 +112,8 @@ class ForwardPlan:
         self.cross_kv_merged = os.environ.get("I2I_CROSS_KV_MERGED", "1") != "0"
         self.fuse_skip = os.environ.get("I2I_FUSE_SKIP", "1") != "0"       # decoder skip convs folded into the upsamplers (A/B hook)
         self.fuse_shortcut = os.environ.get("I2I_FUSE_SHORTCUT", "1") != "0"   # resnet conv_shortcut folded into conv2 (A/B hook)
+        self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
+        self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -400,9 +402,19 @@ class ForwardPlan:
         if C == 512 and self.dtype != torch.float32 and T >= 8 and self.fuse_vae_attention:
             # one head of width 512: the wide-head flash kernel (attention.hip), scores never leave the CU
             o = self.pool.get(B * T * C, self.dtype)
+            # too few query tiles to fill the chip (batch 1: 32 workgroups of 128 queries, all on one XCD): split the KEYS over
+            # ksplit workgroups per query tile and merge (csrc/attention.hip SPLIT); every split keeps >= 8 key tiles of 32
+            nqt, ktiles = B * -(-T // 128), -(-T // 32)
+            ksplit = 1
+            while self.att_ksplit and nqt * ksplit * 2 <= 256 and ktiles % (ksplit * 2) == 0 and ktiles // (ksplit * 2) >= 8 and ksplit < 8:
+                ksplit *= 2
+            ws = self.pool.get(B * ksplit * T * (C + 2), torch.float32) if ksplit > 1 else None
             self._add(O.attention(qk, qk[C:], vt, o, batch=B, heads=1, d=C, tq=T, tk=T, ldq=2 * C, ldk=2 * C, ldvt=Tp, ldo=C,
-                                  q_bs=T * 2 * C, k_bs=T * 2 * C, vt_bs=C * Tp, o_bs=T * C, scale=1.0 / math.sqrt(C)), prefix + ".sdpa",
+                                  q_bs=T * 2 * C, k_bs=T * 2 * C, vt_bs=C * Tp, o_bs=T * C, scale=1.0 / math.sqrt(C),
+                                  ksplit=ksplit if ksplit > 1 else 0, ws=ws), prefix + ".sdpa",
                       4 * B * T * T * C, kernel="attention_wide_kernel")
+            if ws is not None:
+                self.pool.put(ws)
             self.flops += 4 * B * T * T * C
             self.pool.put(qk)
             self.pool.put(vt)
@@ -489,9 +501,26 @@ class ForwardPlan:
             vt, vt_stride = ck["vt"][ck["off"][p] * ldvt:], ck["tot"] * ldvt        # rows off .. off + C of every image's V^T_all
         else:
             wv = pk.conv(p + ".to_v")
-            vt, vt_stride = self.pool.get(vb * C * ldvt, self.dtype), C * ldvt
-            self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
-                              a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T", 2 * vb * tk * C * kv_cin)
+            one = None
+            if ctx is None and self.vt_one_launch and self.flash and d == 64 and wv["b"] is None and tk % 8 == 0:
+                # V^T of ALL images as one plain GEMM, V^T_all [C][B*T] = W_v [C][K] . X [B*T][K]^T (the weight matrix is the row
+                # operand): image b's V^T is the column block b*T .. of every row, which the attention kernel reads through its
+                # strides (ldvt = B*T, batch stride T).  One chip-filling launch on the wide GEMM instead of B weight-row-bound
+                # z-slices of the LDS-DMA igemm.
+                nt = vb * tk
+                vt = self.pool.get(C * nt, self.dtype)
+                one = O.conv(wv["w"], kv_src, vt, nimg=1, hin=1, win=C, ho=1, wo=C, ks=1, c0=kv_cin, lda0=kv_cin, N=nt, ldb=kv_cin, ldc=nt,
+                             tile=53 if C % 256 == 0 else 54)
+                if self.lib.igemm_route(one[1], self.dt) != "gemm_w32_kernel":
+                    self.pool.put(vt)
+                    one = None
+            if one is not None:
+                ldvt, vt_stride = nt, tk
+                self._add(one, p + ".to_v^T", 2 * vb * tk * C * kv_cin, kernel="gemm_w32_kernel")
+            else:
+                vt, vt_stride = self.pool.get(vb * C * ldvt, self.dtype), C * ldvt
+                self._add(O.bgemm(wv["w"], kv_src, vt, M=C, N=tk, Kdim=kv_cin, lda=kv_cin, ldb=kv_cin, ldc=ldvt, batch=vb, heads=1,
+                                  a_bs=(0, 0), b_bs=(kv_bs, 0), c_bs=(C * ldvt, 0)), p + ".to_v^T", 2 * vb * tk * C * kv_cin)
             self.flops += 2 * vb * tk * C * kv_cin
         o = self.pool.get(B * T * C, self.dtype)
         if self.flash and d == 64:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 5
+#define I2I_ABI_VERSION 6
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -160,6 +160,10 @@ typedef struct {
     int32_t batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo;
     int64_t q_bs, k_bs, vt_bs, o_bs; float scale;
     int32_t causal;            /* 1: query i attends to keys <= i (CLIP text tower); needs tq == tk */
+    int32_t ksplit;            /* > 1 (d = 512 kernel only): the keys are divided among ksplit workgroups per query tile and a
+                                  second launch merges the partial results -- for launches with too few query tiles to fill the
+                                  chip (batch 1: 32 tiles of 128 queries on 256 CUs).  Needs `ws`; 0 / 1 = off */
+    void* ws;                  /* fp32 workspace for ksplit: batch*heads*ksplit*tq*(d + 2) floats, 16-byte aligned */
 } i2i_attention_params;
 
 /* Token + position embedding of the CLIP text tower (transformers CLIPTextEmbeddings; the tokenizer side stays on the

@@ -23,7 +23,9 @@ def _emu_builds():
     if not _EMU_BUILDS:
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         import build_emu
-        _EMU_BUILDS["main"] = build_emu.build()
+        # I2I_EMU_TAG: a second object directory (tests/emu/build_<tag>/), so a run against edited sources does not rebuild the
+        # library under a test session that is still using the first one
+        _EMU_BUILDS["main"] = build_emu.build(tag=os.environ.get("I2I_EMU_TAG") or None)
     return _EMU_BUILDS
 
 

@@ -266,7 +266,8 @@ def check_softmax(lib, device, dtype, *, rows=11, cols=77, ldp=80, seed=0):
     return err
 
 
-def check_attention(lib, device, dtype, *, batch=2, heads=2, tq=70, tk=77, d=64, seed=0, spike=False):
+def check_attention(lib, device, dtype, *, batch=2, heads=2, tq=70, tk=77, d=64, seed=0, spike=False, ksplit=0):
+    """ksplit > 1: keys divided among ksplit workgroups per query tile + the merge launch (i2i_attention_params.ksplit, d = 512)."""
     g = torch.Generator().manual_seed(seed)
     C = heads * d
     q = torch.randn(batch, tq, C, generator=g).to(dtype)
@@ -283,8 +284,9 @@ def check_attention(lib, device, dtype, *, batch=2, heads=2, tq=70, tk=77, d=64,
     vt[:, :, :tk] = v.transpose(1, 2)
     qd, kd, vtd = q.to(device), k.to(device), vt.to(device)
     o = torch.full((batch, tq, C), float("nan"), dtype=dtype, device=device)
+    ws = torch.full((batch * heads * ksplit * tq * (d + 2),), float("nan"), device=device) if ksplit > 1 else None
     opcode, p = O.attention(qd, kd, vtd, o, batch=batch, heads=heads, d=d, tq=tq, tk=tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
-                            q_bs=tq * C, k_bs=tk * C, vt_bs=C * ldvt, o_bs=tq * C, scale=1.0 / math.sqrt(d))
+                            q_bs=tq * C, k_bs=tk * C, vt_bs=C * ldvt, o_bs=tq * C, scale=1.0 / math.sqrt(d), ksplit=ksplit, ws=ws)
     run_op(lib, opcode, p, dtype, device)
     got = o.cpu()
     assert torch.isfinite(got.float()).all()

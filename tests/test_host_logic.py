@@ -358,7 +358,8 @@ rank, world, local = dp.init_from_env("gloo")
 lib = _capi.Library(build_emu.build())
 w = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)               # replicated weights: every rank builds the same
 g = torch.Generator().manual_seed(3)
-total = 3                                                           # ragged shards: 2 + 1
+total = 2                                                           # one image per rank (ragged shard bounds: test_data_parallel_two_process_gloo)
+torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))           # two ranks share the host cores
 x = (torch.rand(total, 1, 64, 64, generator=g) < 0.08).float().expand(total, 3, 64, 64).contiguous()
 cap = torch.randn(1, 77, TINY_UNET.cross_attention_dim, generator=g)
 eps = torch.randn(total, 4, 8, 8, generator=g)

@@ -257,6 +257,11 @@ def test_attention_wide_head(emu_lib, dtype):
     wrap-around), query tails, a key tail that is not a chunk multiple (poisoned V^T padding), late max jump."""
     oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)
     oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, d=512, tq=130, tk=64)
+    # keys split over workgroups + merge launch (small-batch VAE attention): 3 key tiles over 2 splits (2 + 1), over 4 (one empty
+    # split: weight 0 in the merge), a late running-max jump inside the last split, two images
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, d=512, tq=70, tk=77, spike=True, ksplit=2)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, d=512, tq=33, tk=96, ksplit=4)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, d=512, tq=20, tk=77, ksplit=4)
 
 
 @pytest.mark.parametrize("wgs", [0, 2])
@@ -387,6 +392,7 @@ def test_w32_conv_three_slabs_one_slab_and_route(emu_lib):
     the kernel the dispatcher picks."""
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=128, h=16, w=32, gn=True, act=1, groups=8, tile=42)
     oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=9, w=32, res=True, alpha=0.5, tile=41)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=20, w=40, res=True, tile=42, seed=5)     # one slab = the last slab: residual rows ride in its load slots
     x = torch.zeros(8, 128, 128, 128, dtype=torch.bfloat16)
     w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16)
     out = torch.zeros(8, 128, 128, 128, dtype=torch.bfloat16)
@@ -461,6 +467,36 @@ def test_gemm_w32_tiles(emu_lib, cfg):
 def test_gemm_w32_geglu(emu_lib, cfg):
     oc.check_geglu(emu_lib, "cpu", torch.bfloat16, tile=cfg, cff=320, rows=300, cin=128)       # N = 640 packed columns
     oc.check_geglu(emu_lib, "cpu", torch.float16, tile=cfg, cff=64, rows=70, cin=64)           # N = 128: one (ragged for 160) column tile
+
+
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+def test_gemm_w32_conv3x3_gather(emu_lib, cfg):
+    """3x3 convolutions as the im2col view of the wide GEMM's A operand (gemm_w32.hip GATHER): the VAE downsamplers'
+    F.pad(0,1,0,1) + stride 2, the UNet downsamplers' stride 2 / pad 1, a stride-1 pad-1 conv; one and two 64-channel stages
+    per tap, ragged row and column tiles, tiles that span images, residual / alpha, both 16-bit types."""
+    bn = 160 if cfg in (51, 52) else 128
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=bn, h=12, w=10, stride=2, asym_pad=True, tile=cfg)             # VAE Downsample2D
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=bn + 40, h=13, w=9, stride=2, pad=1, res=True, alpha=0.6, tile=cfg)   # odd plane, 2 stages / tap
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=3, cin=64, cout=96, h=5, w=7, stride=1, pad=1, bias=False, tile=cfg)           # stride 1, tiles span images
+
+
+@pytest.mark.parametrize("cfg", [53, 54])
+def test_gemm_w32_gn_partials(emu_lib, cfg):
+    """GroupNorm partial sums of the stored output from the wide GEMM's epilogue (128-column tiles): a plain 1x1 and a stride-2
+    3x3 whose row tiles (256 / 128 rows) divide the image; finalised by gn_stats(finalize_only) against statistics of the
+    stored tensor.  Two column tiles, groups of 4 / 16 / 32 channels."""
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=256, h=16, w=16, groups=8, tile=cfg, ks=1)
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.float16, n=1, cin=64, cout=128, h=32, w=32, groups=32, tile=cfg, ks=3, stride=2, res=False)
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=128, h=32, w=32, groups=8, tile=cfg, ks=3, stride=2)
+    # what the kernel cannot do it must decline (the planner then keeps the op on the LDS-DMA igemm): 160-column tiles, ragged row tiles
+    x = torch.zeros(1, 16, 16, 64, dtype=torch.bfloat16)
+    w = torch.zeros(320, 64, dtype=torch.bfloat16)
+    out = torch.zeros(1, 16, 16, 320, dtype=torch.bfloat16)
+    assert emu_lib.igemm_gn_parts(O.conv(x, w, out, nimg=1, hin=16, win=16, ho=16, wo=16, ks=1, tile=51)[1], K.BF16, 32) == 0
+    x2 = torch.zeros(1, 10, 10, 64, dtype=torch.bfloat16)
+    w2 = torch.zeros(128, 64, dtype=torch.bfloat16)
+    out2 = torch.zeros(1, 10, 10, 128, dtype=torch.bfloat16)
+    assert emu_lib.igemm_gn_parts(O.conv(x2, w2, out2, nimg=1, hin=10, win=10, ho=10, wo=10, ks=1, tile=cfg)[1], K.BF16, 32) == 0
 
 
 def test_gemm_w32_routing(emu_lib):

@@ -139,3 +139,7 @@ def test_gemm_w32_waits_and_barriers(async_lib, cfg, order, monkeypatch):
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=64, cin2=128, cout=bn, h=5, w=13, ks=1, pad=0, tile=cfg)           # 3 stages = the ring, two sources
     oc.check_conv(async_lib, "cpu", torch.float16, n=1, cin=128, cout=bn, h=4, w=16, ks=1, pad=0, tile=cfg)                     # 2 stages: shorter than the ring
     oc.check_geglu(async_lib, "cpu", torch.bfloat16, tile=cfg, cff=160, rows=150, cin=256)
+    if cfg <= 54:       # the 3x3 gather (18 stages: the running tap counter across the ring's wraps, zero-block pieces at the borders)
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=bn, h=9, w=11, stride=2, asym_pad=True, tile=cfg)
+    if cfg in (53, 54):
+        oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=128, h=32, w=32, groups=8, tile=cfg, ks=3, stride=2)

@@ -130,6 +130,21 @@ def test_gemm_w32_on_hardware(gpu_lib, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+def test_gemm_w32_conv3x3_gather_on_hardware(gpu_lib, cfg):
+    """The wide GEMM's 3x3 gather (VAE / UNet stride-2 downsamplers) on real asynchrony at the forward's sizes, repeated with
+    fresh seeds; GroupNorm partial sums from its epilogue on the 128-column tiles."""
+    bn = 160 if cfg in (51, 52) else 128
+    for rep in range(2):
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=bn, h=128, w=128, stride=2, asym_pad=True, tile=cfg, seed=rep)        # 18 stages
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=4, cin=320, cout=2 * bn, h=32, w=32, stride=2, pad=1, res=True, alpha=0.5, tile=cfg, seed=rep) # 45 stages
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=1, cin=64, cout=bn + 8, h=37, w=51, stride=1, pad=1, tile=cfg, seed=rep)                  # ragged, odd plane
+    if cfg in (53, 54):
+        oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=128, w=128, groups=32, tile=cfg, ks=3, stride=2, res=False)
+        oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=2, cin=256, cout=256, h=64, w=64, groups=32, tile=cfg, ks=1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
     oc.check_geglu(gpu_lib, "cuda", dtype, tile=20, rows=300, cin=320, cff=1280)
@@ -189,6 +204,10 @@ def test_attention_wide_head(gpu_lib, dtype):
     oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=1, d=512, tq=4096, tk=4096)
     oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=1, d=512, tq=1089, tk=1089, spike=True)      # 33x33 plane
     oc.check_attention(gpu_lib, "cuda", dtype, batch=9, heads=1, d=512, tq=200, tk=77)                     # groups > 8: XCD slots
+    # keys split over workgroups + merge launch: the batch-1 / batch-4 forms the planner picks (8 and 2 splits), a ragged one
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=1, d=512, tq=4096, tk=4096, ksplit=8)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=4, heads=1, d=512, tq=4096, tk=4096, ksplit=2, seed=1)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=1, d=512, tq=1089, tk=1089, spike=True, ksplit=4)
 
 
 @pytest.mark.gpu
