@@ -29,6 +29,9 @@ SHAPES = [  # (name, cin, cout, H, W, ks, stride, ups, gn)
     ("vae down 128@512 s2", 128, 128, 512, 512, 3, 2, 0, 0),
     ("vae down 256@256 s2", 256, 256, 256, 256, 3, 2, 0, 0),
     ("vae down 512@128 s2", 512, 512, 128, 128, 3, 2, 0, 0),
+    ("unet down 320@64 s2", 320, 320, 64, 64, 3, 2, 0, 0),
+    ("unet down 640@32 s2", 640, 640, 32, 32, 3, 2, 0, 0),
+    ("unet down 1280@16 s2", 1280, 1280, 16, 16, 3, 2, 0, 0),
     ("unet 320->320@64 gn", 320, 320, 64, 64, 3, 1, 0, 1),
     ("unet 640->640@32 gn", 640, 640, 32, 32, 3, 1, 0, 1),
     ("unet 1280->1280@16 gn", 1280, 1280, 16, 16, 3, 1, 0, 1),

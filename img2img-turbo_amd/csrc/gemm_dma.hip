@@ -612,6 +612,18 @@ int launch_dma_t(const i2i_igemm_params& p, hipStream_t s) {
 }  // namespace
 
 namespace i2i {
+// The split-K reduce + epilogue launch, shared with the wide GEMM (gemm_w32.hip): out = epilogue(alpha * sum_s ws[s][m][n]).
+int splitk_reduce(const i2i_igemm_params& p, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)p.M * p.N;
+    const dim3 g((unsigned)((total + 1023) / 1024)), b(256);
+    switch (dtype) {
+        case I2I_F32: hipLaunchKernelGGL((splitk_reduce_kernel<float>), g, b, 0, s, p); break;
+        case I2I_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<__bf16>), g, b, 0, s, p); break;
+        case I2I_F16: hipLaunchKernelGGL((splitk_reduce_kernel<_Float16>), g, b, 0, s, p); break;
+        default: return fail(I2I_ERR_BAD_ARG, "splitk_reduce: bad dtype");
+    }
+    return check_launch("splitk_reduce");
+}
 // What the DMA engine takes: no GroupNorm prologue, slab-aligned taps, vector-aligned outputs, 32-bit offsets.
 bool igemm_dma_eligible(const i2i_igemm_params& p, int dtype) {
     const int epc = (dtype == I2I_F32) ? 4 : 8, bk = 8 * epc;

@@ -24,6 +24,10 @@
 #include "i2i_dev.h"
 #include "launch.h"
 
+namespace i2i {
+int splitk_reduce(const i2i_igemm_params& p, int dtype, hipStream_t s);      // gemm_dma.hip: sums the fp32 slices, applies the epilogue
+}
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,9 +72,12 @@ constexpr int G32_NW = 4, G32_BK = 64, G32_KQ = 4;       // waves per workgroup 
 // F.pad(0,1,0,1)) over ONE NHWC source with cin % 64 == 0: stage s = 64 channels of tap s*64 / cin, the tap's pixel offset is
 // a scalar added to the per-lane source offset of every A piece, taps outside the plane read a 16-byte zero block.
 // STATS: the epilogue also emits the GroupNorm partial sums of the STORED output (p.gn_part), one slot per (row tile, group).
-template <typename T, int FMW, int FNW, int RING, bool GEGLU, bool GATHER = false, bool STATS = false>
+// SPLITK: grid y = p.splitk slices of the K stages; every slice writes its raw fp32 accumulators to p.ws [slice][M][N] and
+// splitk_reduce (gemm_dma.hip) sums them in a fixed order and applies the epilogue -- the 3x3 convolutions of the UNet's 8 x 8 /
+// 16 x 16 planes at batch 8 (M = 512 .. 2048 rows against K = 11520 .. 23040: 16 - 32 tiles would leave the chip empty).
+template <typename T, int FMW, int FNW, int RING, bool GEGLU, bool GATHER = false, bool STATS = false, bool SPLITK = false>
 __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igemm_params p) {
-    static_assert(!(GEGLU && (GATHER || STATS)), "");
+    static_assert(!(GEGLU && (GATHER || STATS)) && !(SPLITK && (GEGLU || STATS)), "");
     constexpr int NW = G32_NW, BK = G32_BK, KQ = G32_KQ;
     constexpr int WTM = 32 * FMW, BM = NW * WTM, BN = 32 * FNW;
     constexpr int STAGE = (BM + BN) * 128;
@@ -100,7 +107,15 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const bool m_fast = p.N > p.M;
     const int m0 = (m_fast ? bid % ntm : bid / ntn) * BM, n0 = (m_fast ? bid / ntm : bid % ntn) * BN;
-    const int nk = p.K / BK;                              // K % 64 == 0 (host check)
+    // K % 64 == 0 (host check).  SPLITK: this workgroup's stages are s0 .. s0 + nk - 1 (a slice past the end has nk = 0 and
+    // writes zeros)
+    int s0 = 0, nk = p.K / BK;
+    if constexpr (SPLITK) {
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        s0 = (int)blockIdx.y * per;
+        const int left = nk - s0;
+        nk = left < 0 ? 0 : (left < per ? left : per);
+    }
 
     const char* a0 = (const char*)p.a0;
     const char* a1 = (const char*)p.a1;
@@ -155,12 +170,18 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     // GATHER: (tap, channel offset) of the NEXT window to open -- windows open in stage order, so the decode is a running
     // counter in scalar registers -- and of the open one: tap index (bit of a_ok) and byte offset of (tap pixel, channels)
     int g_tap = 0, g_ky = 0, g_kx = 0, g_ci = 0;
+    if constexpr (GATHER && SPLITK) {                     // the slice's first stage
+        g_tap = (s0 * BK) / p.c0;
+        g_ci = s0 * BK - g_tap * p.c0;
+        g_ky = g_tap / 3;
+        g_kx = g_tap - g_ky * 3;
+    }
     unsigned w_tap = 0u, w_aoff = 0u;
     auto open_window = [&](int s, int slot) __attribute__((always_inline)) {      // s < 0: dummy window
         const bool on = s >= 0;
         if constexpr (!GATHER) {
             const int sa = s >= s_sw ? s - s_sw : s;
-            const char* ab = (s >= s_sw ? a1 : a0) + (size_t)(sa < 0 ? 0 : sa) * (BK * 2);
+            const char* ab = (s >= s_sw ? a1 : a0) + (size_t)(sa < 0 ? 0 : sa + s0) * (BK * 2);      // (SPLITK: one source, s_sw = nk)
             w_abase = on ? ab : zero;
         } else {
             w_tap = (unsigned)g_tap;
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
             g_kx = wrap3 ? 0 : g_kx;
             g_ky += wrap3;
         }
-        w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s) * (BK * 2) : zero;
+        w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s + s0) * (BK * 2) : zero;
         w_msk = on ? 0xffffffffu : 0u;
         w_dst = i2i_smem + slot * STAGE;
         sopaque(w_msk);                                    // (the ksteps must not be specialised on the window kind)
@@ -292,6 +313,22 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     // ---- epilogue.  acc[i][j][r]: row m0 + wave*WTM + i*32 + l31, column n0 + j*32 + 8*(r>>2) + 4*lh + (r&3).  Register quads
     // (2*pr, 2*pr+1) are half-exchanged between lanes l and l+32 (widen_pair): the lane then owns the 8 consecutive columns
     // j*32 + 16*pr + 8*lh .. +7 of its row: 16-byte residual loads and stores.
+    if constexpr (SPLITK) {
+        // raw fp32 partial sums: a register quad is 4 consecutive columns of one row (16-byte stores); N % 8 == 0 (host check)
+        float* __restrict__ ws = (float*)p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FMW; ++i) {
+            const int m = m0 + wave * WTM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < FNW; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + j * 32 + 8 * q + 4 * lh;
+                    if (m < p.M && n < p.N) *(f32x4*)(ws + (int64_t)m * p.N + n) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+        }
+        return;
+    }
     typedef T tx8 __attribute__((ext_vector_type(8)));
     const T* __restrict__ res = (const T*)p.res;
     T* __restrict__ out = (T*)p.c;
@@ -492,16 +529,23 @@ int launch_g32(const i2i_igemm_params& p, hipStream_t s) {
     const size_t smem = (size_t)RING * (BM + BN) * 128;
     const dim3 g(tiles), b(G32_NW * 64);
     const bool gather = p.ks == 3, stats = p.gn_part != nullptr;
-    // (the gather and the statistics epilogue exist for the 3-deep ring only, the statistics for 128-column tiles only:
+    // (the gather, split-K and the statistics epilogue exist for the 3-deep ring only, the statistics for 128-column tiles only:
     // gemm_w32_eligible / gemm_w32_gn_parts admit nothing else)
     if constexpr (RING == 3) {
+        if (p.splitk > 1) {
+            const dim3 gs(tiles, (unsigned)p.splitk);
+            if (gather) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, true, false, true>), gs, b, smem, s, p);
+            else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, false, false, true>), gs, b, smem, s, p);
+            const int rc = i2i::check_launch("gemm_w32<splitk>");
+            return rc != I2I_OK ? rc : i2i::splitk_reduce(p, Elem<T>::DT, s);
+        }
         if constexpr (FNW == 4) {
             if (gather && stats) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, true, true>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<conv,stats>"); }
             if (stats) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, false, true>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<stats>"); }
         }
         if (gather) { hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, true, false>), g, b, smem, s, p); return i2i::check_launch("gemm_w32<conv>"); }
     }
-    if (gather || stats) return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: this tile configuration has no 3x3 gather / statistics epilogue");
+    if (gather || stats || p.splitk > 1) return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: this tile configuration has no 3x3 gather / split-K / statistics epilogue");
     if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true>), g, b, smem, s, p);
     else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false>), g, b, smem, s, p);
     return i2i::check_launch("gemm_w32");
@@ -526,7 +570,7 @@ namespace i2i {
 // GroupNorm partial-sum slots per image the wide GEMM writes for this op (0 = it cannot): the 128-column tiles (53 / 54), row
 // tiles that do not straddle images, channels-per-group a multiple of 4 that divides the 128 columns of a tile.
 static int g32_gn_parts(const i2i_igemm_params& p, int groups) {
-    if (groups < 1 || p.N % groups || p.geglu) return 0;
+    if (groups < 1 || p.N % groups || p.geglu || p.splitk > 1) return 0;      // (split-K: the reduce launch has no statistics)
     const int cfg = g32_cfg(p);
     if (cfg != 53 && cfg != 54) return 0;
     const int bm = g32_geometry(cfg).bm, cpg = p.N / groups, hw = p.ho * p.wo;
@@ -544,7 +588,9 @@ bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (!gather && (p.stride != 1 || p.pad != 0)) return false;
     if (gather && (p.stride < 1 || p.stride > 2 || p.pad < 0 || p.pad > 1 || p.c1 || p.a1 || p.geglu || p.tile == 55 || p.tile == 56)) return false;
     if (p.ups != 0 || p.up_h || p.up_w || p.subpix || p.k2_a) return false;
-    if (p.zcount > 1 || p.splitk > 1 || p.gn_ss || p.act || p.act_out || p.out_f32 || p.bias_mode == 2) return false;
+    if (p.zcount > 1 || p.gn_ss || p.act || p.act_out || p.out_f32 || p.bias_mode == 2) return false;
+    // split-K: only when a caller names one of the 3-deep-ring tiles (tile 0 keeps split-K ops on the LDS-DMA igemm)
+    if (p.splitk > 1 && (!p.ws || (((uintptr_t)p.ws) & 15) || p.c1 || p.geglu || p.gn_part || p.tile < 51 || p.tile > 54 || p.splitk > p.K / G32_BK)) return false;
     const int cin = p.c0 + p.c1;
     if (p.K != p.ks * p.ks * cin || cin % G32_BK || cin < G32_BK || (p.c1 && p.c0 % G32_BK)) return false;
     if (p.lda0 % 8 || (p.a1 && p.lda1 % 8) || p.ldb % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;

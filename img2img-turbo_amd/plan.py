@@ -112,6 +112,14 @@ class ForwardPlan:
         self.cross_kv_merged = os.environ.get("I2I_CROSS_KV_MERGED", "1") != "0"
         self.fuse_skip = os.environ.get("I2I_FUSE_SKIP", "1") != "0"       # decoder skip convs folded into the upsamplers (A/B hook)
         self.fuse_shortcut = os.environ.get("I2I_FUSE_SHORTCUT", "1") != "0"   # resnet conv_shortcut folded into conv2 (A/B hook)
+        # UNet small-plane 3x3 convolutions on the wide GEMM with K slices (A/B hook), bit mask: 1 = the stride-2 downsamplers,
+        # 2 = the 16 x 16 planes the halo conv would take at batch 8 (<= 2048 rows, >= 1024 channels), 4 = the planes no halo tile
+        # fits or fills (8 x 8; 16 x 16 / 32 x 32 at small batch) that were split-K launches of the LDS-DMA igemm; 0 = none
+        self.w32_splitk = int(os.environ.get("I2I_W32_SPLITK", "7"))
+        # (rows / workgroups below which such a conv stays on the LDS-DMA igemm; the emulator tests lower them to reach the route
+        # with a tiny model)
+        self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
+        self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
         lat = self.va.latent_channels
@@ -227,6 +235,27 @@ class ForwardPlan:
             return 0, None
         return sk, self.pool.get(sk * M * N, torch.float32)
 
+    @staticmethod
+    def _w32_splitk_cfg(M, N, Kd, min_wgs=96):
+        """(wide-GEMM tile id, K slices) for a small-plane 3x3 convolution; (0, 0) = leave it on the LDS-DMA igemm.
+        Measured at batch 8 (profiles/r4h_bench_ops_splitk_w32.log vs _dma.log): 512 rows -> 128 x 128 tiles x 6 slices
+        (1280 -> 1280 @ 8 x 8: 0.050 -> 0.034 ms), 2048 rows -> 256 x 160 x 4 when that gives 64 tiles (1280 -> 1280 @ 16 x 16:
+        0.157 -> 0.081 ms) else 128 x 160 x 4 (640 @ 32 x 32 stride 2: 0.055 -> 0.035 ms), 8192 rows -> 128 x 128, one slice
+        (320 @ 64 x 64 stride 2: 0.067 -> 0.033 ms)."""
+        if Kd % 64 or N % 8 or N < 128:
+            return 0, 0
+        stages = Kd // 64
+        if 1024 <= M < 4096 and N % 160 == 0:
+            cfg = 51 if -(-M // 256) * (N // 160) >= 64 else 52
+        else:
+            cfg = 54
+        bm, bn = {51: (256, 160), 52: (128, 160), 54: (128, 128)}[cfg]
+        tiles = -(-M // bm) * -(-N // bn)
+        sk = max(1, min(256 // tiles, stages // 8))
+        if tiles * sk < min_wgs:
+            return 0, 0
+        return cfg, sk
+
     def upsample_conv(self, pk, name, x: Act, label, size=None, k2=None) -> Act:
         """Upsample2D: nearest-2x + 3x3 conv.  Sub-pixel form (4/9 of the MACs, csrc/conv3x3.hip SUBPIX) whenever the
         halo kernel takes it -- slab-aligned channels, source plane of at least one 8x16 tile; else the index-map gather."""
@@ -273,6 +302,11 @@ class ForwardPlan:
             halo_tiles = x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128)
             if halo_tiles < self.halo_min_tiles:
                 halo, force_tile = False, 20
+            elif ((self.w32_splitk & 2) and self.dtype != torch.float32 and x.n * ho * wo <= 2048 and pw["n"] >= 1024 and pw["n"] % 160 == 0
+                  and self.dma_small and not pw.get("subpix")):
+                # 16 x 16 planes at batch 8 (2048 rows x K = 5760 .. 23040): the wide GEMM with 4 K slices runs them at ~750 TFLOP/s
+                # against ~500 of the halo conv's 160 tiles (profiles/r4h_*); GroupNorm + SiLU then come materialised, like below
+                halo, force_tile = False, 20
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
         if gn and not fused:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
@@ -288,11 +322,31 @@ class ForwardPlan:
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         M, N, Kd = x.n * ho * wo, pw["n"], ks * ks * (x.c + c1)
         splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
-        op = O.conv(x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
-                    x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
-                    gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
-                    res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
-                    splitk=splitk, ws=ws, subpix=subpix, tile=force_tile, up_size=up_size)
+        mk = lambda tile_, splitk_, ws_: O.conv(
+            x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
+            x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
+            gn_ss=None, act=act if fused else 0, bias=pw["b"], alpha=alpha,
+            res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
+            splitk=splitk_, ws=ws_, subpix=subpix, tile=tile_, up_size=up_size)
+        op = None
+        took16 = force_tile == 20 and x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128) >= self.halo_min_tiles      # (bit 2 above)
+        want = (self.w32_splitk & 1) if stride == 2 else ((self.w32_splitk & 2) if took16 else (self.w32_splitk & 4))
+        if (want and ks == 3 and stride in (1, 2) and not (halo or fused or geglu or ups or out_f32) and self.dtype != torch.float32
+                and x_in1 is None and self.w32_splitk_min_rows <= M <= 16384):      # (more rows: tile 0 finds the wide GEMM by itself)
+            # UNet small-plane / stride-2 3x3 convolutions on the wide GEMM (csrc/gemm_w32.hip: im2col gather + K slices): the tile
+            # and slice count that put ~256 workgroups on the chip with >= 8 stages each (sweep: profiles/r4h_bench_ops_splitk_*)
+            cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs)
+            if cfg:
+                ws2 = self.pool.get(sk * M * N, torch.float32) if sk > 1 else None
+                cand = mk(cfg, sk if sk > 1 else 0, ws2)
+                if self.lib.igemm_route(cand[1], self.dt) == "gemm_w32_kernel":
+                    if ws is not None:
+                        self.pool.put(ws)
+                    op, ws = cand, ws2
+                elif ws2 is not None:
+                    self.pool.put(ws2)
+        if op is None:
+            op = mk(force_tile, splitk, ws)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
         out.producer = op[1]

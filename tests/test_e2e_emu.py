@@ -28,7 +28,7 @@ def test_pix2pix_deterministic_fp32(emu_lib):
 
 
 @pytest.mark.slow
-def test_pix2pix_stochastic_twinconv_bf16(emu_lib):
+def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=2, sketch=True)
     x, cap, eps, nm = make_inputs("sketch", 1, 64, 64, TINY_UNET.cross_attention_dim)
     ref = pix2pix_forward(mw, x, cap, eps, deterministic=False, r=0.4, noise_map=nm)
@@ -36,6 +36,17 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib):
     out = model(x, caption_enc=cap, eps=eps, deterministic=False, r=0.4, noise_map=nm)
     err = (out.float() - ref).abs().max().item()
     assert err < 0.25, err   # bf16 end-to-end, x14.6 scheduler amplification
+    # the batch-8 route of the UNet's small-plane / stride-2 3x3 convolutions (wide GEMM with the im2col gather and K slices,
+    # materialised GroupNorm) reached with the tiny model by lowering the planner's row / workgroup thresholds
+    monkeypatch.setenv("I2I_W32_SPLITK_MIN_ROWS", "1")
+    monkeypatch.setenv("I2I_W32_SPLITK_MIN_WGS", "1")
+    model2 = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.bfloat16, lib=emu_lib)
+    out2 = model2(x, caption_enc=cap, eps=eps, deterministic=False, r=0.4, noise_map=nm)
+    plan2 = list(model2._plans.values())[0]
+    sliced = [p for (_o, _d, p, _l), k in zip(plan2.prog.ops, plan2.op_kernel) if k == "gemm_w32_kernel" and getattr(p, "ks", 0) == 3]
+    assert len(sliced) >= 6 and any(p.splitk > 1 for p in sliced), len(sliced)
+    err2 = (out2.float() - ref).abs().max().item()
+    assert err2 < 0.25, err2
 
 
 @pytest.mark.slow

@@ -480,6 +480,26 @@ def test_gemm_w32_conv3x3_gather(emu_lib, cfg):
     oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=3, cin=64, cout=96, h=5, w=7, stride=1, pad=1, bias=False, tile=cfg)           # stride 1, tiles span images
 
 
+@pytest.mark.parametrize("cfg", [51, 52, 53, 54])
+def test_gemm_w32_splitk(emu_lib, cfg):
+    """Split-K slices of the wide GEMM (grid y) + the shared reduce / epilogue launch: the UNet's small-plane 3x3 convolutions
+    (18 stages over 3 slices, over 4 slices of 5 + 5 + 5 + 3), a slice count that leaves the last slice empty (9 stages over
+    4 slices of 3), a plain 1x1 with residual and alpha; ragged tiles."""
+    bn = 160 if cfg in (51, 52) else 128
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=bn + 8, h=8, w=8, res=True, tile=cfg, splitk=3)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=bn, h=9, w=7, stride=2, pad=1, tile=cfg, splitk=4)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=96, h=6, w=6, bias=False, tile=cfg, splitk=4)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=320, cout=bn, h=5, w=9, ks=1, pad=0, res=True, alpha=0.7, tile=cfg, splitk=2)
+    # a sliced launch has no statistics epilogue (the planner must not attach gn_part to it), and tile 0 keeps split-K ops on the LDS-DMA igemm
+    x = torch.zeros(1, 16, 16, 128, dtype=torch.bfloat16)
+    w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16)
+    out = torch.zeros(1, 16, 16, 128, dtype=torch.bfloat16)
+    ws = torch.zeros(2 * 256 * 128)
+    mk = lambda **kw: O.conv(x, w, out, nimg=1, hin=16, win=16, ho=16, wo=16, ks=3, pad=1, splitk=2, ws=ws, **kw)[1]
+    assert emu_lib.igemm_route(mk(tile=cfg), K.BF16) == "gemm_w32_kernel" and emu_lib.igemm_gn_parts(mk(tile=cfg), K.BF16, 32) == 0
+    assert emu_lib.igemm_route(mk(tile=20), K.BF16) == "igemm_dma_kernel"
+
+
 @pytest.mark.parametrize("cfg", [53, 54])
 def test_gemm_w32_gn_partials(emu_lib, cfg):
     """GroupNorm partial sums of the stored output from the wide GEMM's epilogue (128-column tiles): a plain 1x1 and a stride-2

@@ -141,5 +141,7 @@ def test_gemm_w32_waits_and_barriers(async_lib, cfg, order, monkeypatch):
     oc.check_geglu(async_lib, "cpu", torch.bfloat16, tile=cfg, cff=160, rows=150, cin=256)
     if cfg <= 54:       # the 3x3 gather (18 stages: the running tap counter across the ring's wraps, zero-block pieces at the borders)
         oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=bn, h=9, w=11, stride=2, asym_pad=True, tile=cfg)
+    if cfg <= 54:       # split-K slices start mid-K (the tap counter of the gather starts at the slice's first stage)
+        oc.check_conv(async_lib, "cpu", torch.bfloat16, n=1, cin=128, cout=bn, h=8, w=8, res=True, tile=cfg, splitk=4)
     if cfg in (53, 54):
         oc.check_conv_gn_part(async_lib, "cpu", torch.bfloat16, n=1, cin=64, cout=128, h=32, w=32, groups=8, tile=cfg, ks=3, stride=2)

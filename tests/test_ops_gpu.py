@@ -139,6 +139,8 @@ def test_gemm_w32_conv3x3_gather_on_hardware(gpu_lib, cfg):
         oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=bn, h=128, w=128, stride=2, asym_pad=True, tile=cfg, seed=rep)        # 18 stages
         oc.check_conv(gpu_lib, "cuda", torch.float16, n=4, cin=320, cout=2 * bn, h=32, w=32, stride=2, pad=1, res=True, alpha=0.5, tile=cfg, seed=rep) # 45 stages
         oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=1, cin=64, cout=bn + 8, h=37, w=51, stride=1, pad=1, tile=cfg, seed=rep)                  # ragged, odd plane
+        oc.check_conv(gpu_lib, "cuda", torch.bfloat16, n=8, cin=1280, cout=1280, h=8, w=8, res=True, tile=cfg, splitk=12, seed=rep)                # split-K: 180 stages over 12 slices
+        oc.check_conv(gpu_lib, "cuda", torch.float16, n=8, cin=640, cout=640, h=32, w=32, stride=2, pad=1, tile=cfg, splitk=7, seed=rep)            # 90 stages over 7 slices (13 x 6 + 12)
     if cfg in (53, 54):
         oc.check_conv_gn_part(gpu_lib, "cuda", torch.bfloat16, n=2, cin=128, cout=128, h=128, w=128, groups=32, tile=cfg, ks=3, stride=2, res=False)
         oc.check_conv_gn_part(gpu_lib, "cuda", torch.float16, n=2, cin=256, cout=256, h=64, w=64, groups=32, tile=cfg, ks=1)
