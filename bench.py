@@ -71,9 +71,10 @@ def source_hash():
 def kernel_roofline(plan, dtype_name, reps=2):
     """HIP-event time of every launch of the program (i2i_run_timed: events recorded on the stream the kernels
     run on), grouped by the HIP kernel each op resolves to (plan.op_kernel = i2i_igemm_route for the contractions).
-    The dominant family is the 3x3 stride-1 convolution: `conv3x3_w32_kernel` (csrc/conv3x3_w32.hip, wide tiles on
-    32x32x16 MFMA, incl. its sub-pixel Upsample2D form) plus `conv3x3_halo_kernel` (csrc/conv3x3.hip) for the planes /
-    channel counts the wide tiles do not take.  `achieved` = the family's ALGORITHMIC FLOPs (2*9*Cin*Cout per output
+    The dominant family is the 3x3 stride-1 convolution of the VAE: `conv3x3_w32_kernel` (csrc/conv3x3_w32.hip, wide tiles on
+    32x32x16 MFMA, incl. its sub-pixel Upsample2D form) plus `conv3x3_halo_kernel` (csrc/conv3x3.hip) for what the wide tiles
+    do not take (since round 4 only the three conv_out launches: the UNet's 3x3 convolutions run on `gemm_w32_kernel`, whose
+    rate is in `kernel_breakdown_ms`).  `achieved` = the family's ALGORITHMIC FLOPs (2*9*Cin*Cout per output
     pixel) / its measured time; `executed` prices the sub-pixel launches at the 4/9 of the 3x3 MACs
     the matrix pipe really runs (plan.op_flops_exec).  Every other MFMA family gets the same two numbers in
     `kernel_breakdown_ms` (attention: 4*heads*Tq*Tk*d per image)."""
@@ -110,8 +111,9 @@ def kernel_roofline(plan, dtype_name, reps=2):
         # only for the build and workload the counters were collected on; anything else reports null rather than a stale number
         if tj.get("batch") == plan.B and tj.get("dtype") == dtype_name and tj.get("size") == plan.H and tj.get("source_hash") == source_hash():
             traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("collected")
-    roof = {"bound": "mfma", "kernel": "conv3x3_w32_kernel[<SUBPIX>] + conv3x3_halo_kernel[<SUBPIX>] (every 3x3 stride-1 conv of the step: wide-tile 32x32x16-MFMA "
-                                       "kernel incl. the sub-pixel upsampler form, halo kernel for small planes / odd channel counts)",
+    roof = {"bound": "mfma", "kernel": "conv3x3_w32_kernel[<SUBPIX>] + conv3x3_halo_kernel[<SUBPIX>] (the conv3x3_* launches of the step: the VAE's 3x3 stride-1 convs on the "
+                                       "wide-tile 32x32x16-MFMA kernel incl. the sub-pixel upsampler form, plus whatever the halo kernel still takes -- the conv_out "
+                                       "launches, small planes at small batch, the exact-f32 mode; the UNet's 3x3 convs run on gemm_w32_kernel: kernel_breakdown_ms)",
             "per_kernel": {k: {"launches": fam[k][2], "avg_launch_ms": round(fam[k][0] / fam[k][2], 4),
                                "tflops": round(fam[k][1] / (fam[k][0] * 1e-3) / 1e12, 1)} for k in halo},
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

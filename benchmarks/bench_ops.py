@@ -34,6 +34,8 @@ SHAPES = [  # (name, cin, cout, H, W, ks, stride, ups, gn)
     ("unet down 1280@16 s2", 1280, 1280, 16, 16, 3, 2, 0, 0),
     ("unet 320->320@64 gn", 320, 320, 64, 64, 3, 1, 0, 1),
     ("unet 640->640@32 gn", 640, 640, 32, 32, 3, 1, 0, 1),
+    ("unet 960->320@64 gn", 960, 320, 64, 64, 3, 1, 0, 1),
+    ("unet 1280->640@32 gn", 1280, 640, 32, 32, 3, 1, 0, 1),
     ("unet 1280->1280@16 gn", 1280, 1280, 16, 16, 3, 1, 0, 1),
     ("unet 1280->1280@8 gn", 1280, 1280, 8, 8, 3, 1, 0, 1),
     ("unet 2560->1280@8 gn", 2560, 1280, 8, 8, 3, 1, 0, 1),

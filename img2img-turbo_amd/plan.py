@@ -114,8 +114,9 @@ class ForwardPlan:
         self.fuse_shortcut = os.environ.get("I2I_FUSE_SHORTCUT", "1") != "0"   # resnet conv_shortcut folded into conv2 (A/B hook)
         # UNet small-plane 3x3 convolutions on the wide GEMM with K slices (A/B hook), bit mask: 1 = the stride-2 downsamplers,
         # 2 = the 16 x 16 planes the halo conv would take at batch 8 (<= 2048 rows, >= 1024 channels), 4 = the planes no halo tile
-        # fits or fills (8 x 8; 16 x 16 / 32 x 32 at small batch) that were split-K launches of the LDS-DMA igemm; 0 = none
-        self.w32_splitk = int(os.environ.get("I2I_W32_SPLITK", "7"))
+        # fits or fills (8 x 8; 16 x 16 / 32 x 32 at small batch) that were split-K launches of the LDS-DMA igemm, 8 = every other 3x3
+        # conv of the UNet (32 x 32 / 64 x 64 planes at batch 8: whole 160-column tiles instead of 2.5 / 5 halo channel tiles); 0 = none
+        self.w32_splitk = int(os.environ.get("I2I_W32_SPLITK", "15"))
         # (rows / workgroups below which such a conv stays on the LDS-DMA igemm; the emulator tests lower them to reach the route
         # with a tiny model)
         self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
@@ -241,17 +242,19 @@ class ForwardPlan:
         Measured at batch 8 (profiles/r4h_bench_ops_splitk_w32.log vs _dma.log): 512 rows -> 128 x 128 tiles x 6 slices
         (1280 -> 1280 @ 8 x 8: 0.050 -> 0.034 ms), 2048 rows -> 256 x 160 x 4 when that gives 64 tiles (1280 -> 1280 @ 16 x 16:
         0.157 -> 0.081 ms) else 128 x 160 x 4 (640 @ 32 x 32 stride 2: 0.055 -> 0.035 ms), 8192 rows -> 128 x 128, one slice
-        (320 @ 64 x 64 stride 2: 0.067 -> 0.033 ms)."""
+        (320 @ 64 x 64 stride 2: 0.067 -> 0.033 ms); against the halo conv (r4k_*): 32768 rows x 320 -> 256 x 160, one slice (0.091 ->
+        0.065 ms, 960 -> 320: 0.240 -> 0.162), 8192 rows x 640 -> 128 x 160 (0.090 -> 0.072, 1280 -> 640: 0.175 -> 0.125)."""
         if Kd % 64 or N % 8 or N < 128:
             return 0, 0
         stages = Kd // 64
-        if 1024 <= M < 4096 and N % 160 == 0:
-            cfg = 51 if -(-M // 256) * (N // 160) >= 64 else 52
+        if M >= 1024 and N % 160 == 0:
+            # 256 x 160 tiles when they alone fill the chip (or, with 4 slices, a 2048-row op), 128 x 160 otherwise
+            cfg = 51 if -(-M // 256) * (N // 160) >= (192 if M >= 4096 else 64) else 52
         else:
             cfg = 54
         bm, bn = {51: (256, 160), 52: (128, 160), 54: (128, 128)}[cfg]
         tiles = -(-M // bm) * -(-N // bn)
-        sk = max(1, min(256 // tiles, stages // 8))
+        sk = 1 if tiles >= 128 else max(1, min(256 // tiles, stages // 8))      # (half a round of tiles beats slicing a short K)
         if tiles * sk < min_wgs:
             return 0, 0
         return cfg, sk
@@ -297,16 +300,22 @@ class ForwardPlan:
                 and wo >= 16 and ho >= 8)
         # ... but a halo launch that cannot fill the chip (few 8x16x128 tiles: the 16x16 / 32x32 UNet planes at
         # small batch) is a weight-streaming problem: the LDS-DMA igemm with split-K takes it (tile 20 forces it)
-        force_tile = 0
+        force_tile, grp = 0, 0      # grp: which group of the I2I_W32_SPLITK mask took the op away from the halo conv (0 = none)
         if halo and not pw.get("subpix"):
             halo_tiles = x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128)
+            wide_ok = (self.dtype != torch.float32 and self.dma_small and pw["n"] % 160 == 0
+                       and x.n * hin * win * (x.c + c1) * 2 < (1 << 32))          # (what gemm_w32_eligible will ask of the materialised operand)
             if halo_tiles < self.halo_min_tiles:
-                halo, force_tile = False, 20
-            elif ((self.w32_splitk & 2) and self.dtype != torch.float32 and x.n * ho * wo <= 2048 and pw["n"] >= 1024 and pw["n"] % 160 == 0
-                  and self.dma_small and not pw.get("subpix")):
-                # 16 x 16 planes at batch 8 (2048 rows x K = 5760 .. 23040): the wide GEMM with 4 K slices runs them at ~750 TFLOP/s
-                # against ~500 of the halo conv's 160 tiles (profiles/r4h_*); GroupNorm + SiLU then come materialised, like below
-                halo, force_tile = False, 20
+                halo, force_tile, grp = False, 20, 4
+            elif (self.w32_splitk & 2) and wide_ok and x.n * ho * wo <= 2048 and pw["n"] >= 1024:
+                # 16 x 16 planes at batch 8 (2048 rows x K = 5760 .. 23040): the wide GEMM with 4 K slices runs them at 740 - 920
+                # TFLOP/s against ~500 of the halo conv's 160 tiles (profiles/r4h_*, r4i_per_op_*); GroupNorm + SiLU then come
+                # materialised, like below
+                halo, force_tile, grp = False, 20, 2
+            elif (self.w32_splitk & 8) and wide_ok:
+                # the UNet's 32 x 32 / 64 x 64 planes (320 / 640 output channels: 2.5 / 5 halo channel tiles, 650 - 750 TFLOP/s) on
+                # 256 x 160 / 128 x 160 wide-GEMM tiles: 930 - 1115 TFLOP/s before the extra gn_apply pass (profiles/r4k_*)
+                halo, force_tile, grp = False, 20, 8
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
         if gn and not fused:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
@@ -329,10 +338,9 @@ class ForwardPlan:
             res=res.t if res else None, ldr=res.c if res else None, ldc=out.c, geglu=geglu, out_f32=out_f32,
             splitk=splitk_, ws=ws_, subpix=subpix, tile=tile_, up_size=up_size)
         op = None
-        took16 = force_tile == 20 and x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128) >= self.halo_min_tiles      # (bit 2 above)
-        want = (self.w32_splitk & 1) if stride == 2 else ((self.w32_splitk & 2) if took16 else (self.w32_splitk & 4))
+        want = ((self.w32_splitk & 1) and M <= 16384) if stride == 2 else (self.w32_splitk & (grp or 4))      # (VAE downsamplers: tile 0 finds the wide GEMM by itself)
         if (want and ks == 3 and stride in (1, 2) and not (halo or fused or geglu or ups or out_f32) and self.dtype != torch.float32
-                and x_in1 is None and self.w32_splitk_min_rows <= M <= 16384):      # (more rows: tile 0 finds the wide GEMM by itself)
+                and x_in1 is None and M >= self.w32_splitk_min_rows):
             # UNet small-plane / stride-2 3x3 convolutions on the wide GEMM (csrc/gemm_w32.hip: im2col gather + K slices): the tile
             # and slice count that put ~256 workgroups on the chip with >= 8 stages each (sweep: profiles/r4h_bench_ops_splitk_*)
             cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs)
@@ -343,8 +351,10 @@ class ForwardPlan:
                     if ws is not None:
                         self.pool.put(ws)
                     op, ws = cand, ws2
-                elif ws2 is not None:
-                    self.pool.put(ws2)
+                else:
+                    assert grp not in (2, 8), (label, "taken from the halo conv for a wide-GEMM route that does not exist")
+                    if ws2 is not None:
+                        self.pool.put(ws2)
         if op is None:
             op = mk(force_tile, splitk, ws)
         if ws is not None:
