@@ -6,8 +6,8 @@
 #   3. HBM traffic of the halo conv launches: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), corrected per
 #      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3.json keyed on the kernel-source hash
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
-TAG=${1:-r3}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency"
+TAG=${1:-r4}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
+CMD="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
 cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err
@@ -18,9 +18,9 @@ python tools/pmc_traffic.py $F $W conv3x3_ --batch 8 --dtype bf16 --size 512 --s
 cp $O/${TAG}_traffic_conv3x3.json profiles/traffic_conv3x3.json
 python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
 python bench.py --batch 1 --no-cpu-baseline > $O/${TAG}_bench_bs1.json 2>> $O/${TAG}_bench_bs8.err
-python bench.py --batch 32 --no-cpu-baseline --steps 20 > $O/${TAG}_bench_bs32.json 2>> $O/${TAG}_bench_bs8.err
-python bench.py --model cyclegan --batch 4 > $O/${TAG}_bench_cfg3_cyclegan_bs4.json 2>> $O/${TAG}_bench_bs8.err
-python bench.py --stochastic --gamma 0.4 --batch 16 > $O/${TAG}_bench_cfg4_stochastic_bs16.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --batch 32 --no-cpu-baseline --steps 10 > $O/${TAG}_bench_bs32.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --model cyclegan --batch 4 --no-cpu-baseline > $O/${TAG}_bench_cfg3_cyclegan_bs4.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --stochastic --gamma 0.4 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_cfg4_stochastic_bs16.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --size 1024 --dtype f16 --batch 8 --steps 10 --no-cpu-baseline > $O/${TAG}_bench_cfg5_1024_f16_bs8.json 2>> $O/${TAG}_bench_bs8.err
 for f in $O/${TAG}_bench_*.json; do python - "$f" <<'PY'
 import json, sys
@@ -40,3 +40,8 @@ cp $(find $O/${TAG}_trace_bs1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_ben
 timeout 600 bash benchmarks/pmc_conv.sh $O/${TAG}_pmc "vae 128->128@512 gn,vae 512->512@128 gn" > /dev/null 2>&1
 python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc/sq2 -name "*counter_collection.csv" | head -1) conv3x3_ > $O/${TAG}_pmc_conv3x3_summary.txt 2>&1
 cat $O/${TAG}_pmc_conv3x3_summary.txt
+# 7. SQ + HBM counters of the wide GEMM (gemm_w32.hip) on its characteristic shapes: the GEGLU / ff.net.2 projections (tile 0 = auto) and the UNet's
+#    3x3 convolutions through its im2col gather (256 x 160 tiles)
+timeout 500 bash benchmarks/pmc_conv.sh $O/${TAG}_pmc_g32 "unet lin 1280->10240 T256,unet lin 1280->320 T4096,unet 960->320@64 gn,unet 320->320@64 gn" "--nogn --tiles 51" > /dev/null 2>&1
+python tools/pmc_summary.py $(find $O/${TAG}_pmc_g32 -name "*counter_collection.csv" | sort | tr '\n' ' ') gemm_w32_kernel > $O/${TAG}_pmc_gemm_w32_summary.txt 2>&1
+cat $O/${TAG}_pmc_gemm_w32_summary.txt
