@@ -411,3 +411,28 @@ def test_product_and_oracle_twins_of_arch_and_synth_agree():
                 assert list(sx) == list(sy), part
                 assert all(torch.equal(sx[k], sy[k]) for k in sx), part
         assert x.unet_scaling == y.unet_scaling and x.vae_scaling == y.vae_scaling
+
+
+def test_wide_gemm_tile_rule_for_the_unet_convs():
+    """The planner's (tile, K slices) choice for a 3x3 conv on the wide GEMM reproduces what the sweeps measured best or within 10 % of it
+    (profiles/r4h_bench_ops_splitk_w32.log, r4k_bench_ops_unet_planes_w32.log), keeps every slice at >= 8 stages, and declines ops that would
+    put fewer than ~100 workgroups on the chip (they stay on the LDS-DMA igemm's split-K)."""
+    from img2img_turbo_amd.plan import ForwardPlan
+    rule = ForwardPlan._w32_splitk_cfg
+    measured = {                                    # (rows, N, K) at batch 8 -> (tile, slices)
+        (512, 1280, 11520): (54, 6),                # 1280 -> 1280 @ 8 x 8: 0.034 ms (LDS-DMA igemm 0.050)
+        (512, 1280, 23040): (54, 6),                # 2560 -> 1280 @ 8 x 8: 0.049 (0.084)
+        (2048, 1280, 11520): (51, 4),               # 1280 -> 1280 @ 16 x 16: 0.081 (0.157; halo conv 0.125)
+        (2048, 640, 5760): (52, 4),                 # 640 @ 32 x 32 stride 2: 0.035 (0.055)
+        (8192, 640, 5760): (52, 1),                 # 640 -> 640 @ 32 x 32: 0.072 (halo conv 0.090)
+        (8192, 640, 11520): (52, 1),                # 1280 -> 640 @ 32 x 32: 0.125 (0.175)
+        (32768, 320, 2880): (51, 1),                # 320 -> 320 @ 64 x 64: 0.065 (0.091)
+        (32768, 320, 8640): (51, 1),                # 960 -> 320 @ 64 x 64: 0.162 (0.240)
+    }
+    for (m, n, k), want in measured.items():
+        assert rule(m, n, k) == want, (m, n, k, rule(m, n, k))
+    for m, n, k in [(512, 1280, 11520), (1024, 640, 5760), (2048, 1280, 23040), (4096, 320, 2880), (256, 1280, 11520)]:
+        cfg, sk = rule(m, n, k, 1)
+        assert cfg in (51, 52, 54) and sk >= 1 and (k // 64) // sk >= 8, (m, n, k, cfg, sk)
+    assert rule(64, 1280, 11520) == (54, 22) and rule(64, 320, 2880) == (0, 0)      # 10 x 22 = 220 workgroups vs 3 x 5 = 15: declined
+    assert rule(512, 100, 1152) == (0, 0) and rule(512, 1280, 100) == (0, 0)          # not a 64-stage K / too narrow
