@@ -303,7 +303,7 @@ class ForwardPlan:
         force_tile, grp = 0, 0      # grp: which group of the I2I_W32_SPLITK mask took the op away from the halo conv (0 = none)
         if halo and not pw.get("subpix"):
             halo_tiles = x.n * -(-ho // 8) * -(-wo // 16) * -(-pw["n"] // 128)
-            wide_ok = (self.dtype != torch.float32 and self.dma_small and pw["n"] % 160 == 0 and not ups
+            wide_ok = (self.dtype != torch.float32 and self.dma_small and pw["n"] % 160 == 0 and not ups and (gn or x1 is None)
                        and x.n * hin * win * (x.c + c1) * 2 < (1 << 32))          # (what gemm_w32_eligible will ask of the materialised operand)
             if halo_tiles < self.halo_min_tiles:
                 halo, force_tile, grp = False, 20, 4
