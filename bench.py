@@ -84,12 +84,13 @@ def kernel_roofline(plan, dtype_name, reps=2):
         ms = cur if ms is None else [min(a, b) for a, b in zip(ms, cur)]
     tot = sum(ms)
     fam = {}
-    for name, t, fl, fx in zip(plan.op_kernel, ms, plan.op_flops, plan.op_flops_exec):
-        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+    for name, t, fl, fx, nb in zip(plan.op_kernel, ms, plan.op_flops, plan.op_flops_exec, plan.op_bytes):
+        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
         f[0] += t
         f[1] += fl
         f[2] += 1
         f[3] += fx
+        f[4] += nb
     if PER_OP_PATH:
         rows = sorted(((t, label, kn, fl) for (opc, _dt, _p, label), kn, t, fl in zip(plan.prog.ops, plan.op_kernel, ms, plan.op_flops)), reverse=True)
         with open(PER_OP_PATH, "w") as f:
@@ -125,8 +126,12 @@ def kernel_roofline(plan, dtype_name, reps=2):
             "traffic_source": traffic_src,
             "launches": n3, "avg_launch_ms": round(t3 / n3, 4), "share_of_step_time": round(t3 / tot, 3),
             "algorithmic_flops_per_launch": f3 / n3, "executed_mfma_flops_per_step": getattr(plan, "halo_flops_real", None)}
+    # MFMA families: algorithmic TFLOP/s against the dense peak; HBM-bound families (norms, layout / latent ops: plan.op_bytes =
+    # one read [+ one write] per element): algorithmic GB/s against the 8 TB/s HBM3E peak
     breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None,
-                     "frac_of_mfma_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4) if v[1] else None}
+                     "frac_of_mfma_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4) if v[1] else None,
+                     "gbytes_per_s": round(v[4] / (v[0] * 1e-3) / 1e9, 1) if (v[4] and not v[1]) else None,
+                     "frac_of_hbm_peak": round(v[4] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (v[4] and not v[1]) else None}
                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     return roof, breakdown, tot
 
@@ -184,6 +189,7 @@ def main():
     ap.add_argument("--gamma", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32-mode replays (images_per_s_f32 / parity_max_abs_f32) of the N = 1 line")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--serial-gather", action="store_true", help="N > 1: gather straight from the plan's output buffer on the launch stream (no overlap with the next replay)")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
@@ -351,6 +357,32 @@ def main():
                     lat.append((time.perf_counter() - t) * 1e3)
                 rec["latency_bs%d_ms_p50" % lb] = round(statistics.median(lat), 3)
                 rec["latency_bs%d_ms_per_image_p50" % lb] = round(statistics.median(lat) / lb, 3)
+        out32 = None
+        if a.dtype != "f32" and not a.no_f32 and a.arch == "sd-turbo":
+            # north_star's 1e-3 bound is met by the exact-f32 MFMA mode (v_mfma_f32_16x16x4_f32 = an fmaf chain): its throughput and
+            # its parity ride in the same line, a few replays of the same batch (roofline against the 157.3 TFLOP/s f32 peak)
+            m32 = type(model)(weights=weights, device=dev, dtype=torch.float32)
+            p32 = (m32.get_plan(B, a.size, a.size, direction=a.direction) if a.model == "cyclegan" else
+                   m32.get_plan(B, a.size, a.size, stochastic=a.stochastic, r=a.gamma))
+            m32.stage(p32, xd, cap.to(dev), eps.to(dev), noise.to(dev) if a.stochastic else None)
+            for _ in range(2):
+                p32.replay()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                p32.replay()
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t) / 3
+            out32 = p32.out[:1].float().cpu()
+            rec["images_per_s_f32"] = round(B / dt32, 2)
+            rec["ms_per_step_f32"] = round(dt32 * 1e3, 2)
+            if falg:
+                rec["e2e_mfma_frac_f32"] = round(B / dt32 * falg / 1e12 / PEAK_TF["f32"], 4)
+            rec["f32_note"] = ("the same batch through the exact-f32 MFMA mode (fp32 activations and weights, 157.3 TFLOP/s peak): 3 hipGraph "
+                               "replays after 2 warm-ups; parity_max_abs_f32 = its image 0 vs the CPU fp32 oracle")
+            m32.release_plans()
+            del m32, p32
+            torch.cuda.empty_cache()
         if not a.no_cpu_baseline:
             cb, ref = cpu_baseline(a, weights, x, cap, eps, noise)
             rec["cpu_baseline"] = cb
@@ -360,6 +392,8 @@ def main():
             rec["parity_mean_abs"] = round(float(d.mean()), 6)
             rec["parity_psnr_db"] = round(10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20))).item(), 2)
             rec["parity_note"] = "GPU %s image 0 of the benchmarked batch vs the CPU fp32 oracle on the same inputs, outputs in [-1,1]" % a.dtype
+            if out32 is not None:
+                rec["parity_max_abs_f32"] = round(float((out32 - ref).abs().max()), 7)
     print(json.dumps(rec), flush=True)
 
 

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--res", action="store_true", help="add a residual tensor in the epilogue (the resnets' conv2)")
     ap.add_argument("--nogn", action="store_true", help="drop the GroupNorm prologue (paths that need a materialised input)")
     ap.add_argument("--geglu", action="store_true", help="1x1 shapes with N % 32 == 0: GEGLU epilogue (ff.net.0 of the transformer blocks; output N/2 columns)")
+    ap.add_argument("--fill", default="randn", choices=["randn", "zero", "const"], help="operand fill: the chip clocks to its power budget, and data toggling is part of it "
+                    "(MI355X_MICROARCH.md 'DVFS give-back'): zero / constant operands show how much of a kernel's time is clock, not cycles")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = 157.3 if a.dtype == "f32" else 2500.0
@@ -84,6 +86,9 @@ def main():
         B = a.batch
         x = torch.randn(B, H, W, cin, device=dev).to(dt)
         w = (torch.randn(cout, ks * ks * cin, device=dev) / math.sqrt(ks * ks * cin)).to(dt)
+        if a.fill != "randn":
+            x = torch.full_like(x, 0.0 if a.fill == "zero" else 0.5)
+            w = torch.full_like(w, 0.0 if a.fill == "zero" else 0.01)
         sp = 1 if (a.subpix and ups == 1 and ks == 3) else 0
         if sp:
             w = (torch.randn(4 * cout, 4 * cin, device=dev) / math.sqrt(4 * cin)).to(dt)

@@ -37,7 +37,7 @@ class IgemmParams(C.Structure):
 class GnStatsParams(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("c0", i32), ("c1", i32), ("ld0", i32), ("ld1", i32),
                 ("nimg", i32), ("hw", i32), ("groups", i32), ("eps", f32),
-                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp), ("finalize_only", i32)]
+                ("gamma", vp), ("beta", vp), ("partial", vp), ("nparts", i32), ("ss", vp), ("finalize_only", i32), ("counters", vp)]
 
 
 class GnApplyParams(C.Structure):
@@ -180,7 +180,7 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 6:
+        if L.i2i_abi_version() != 7:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))

@@ -23,6 +23,10 @@
 //     vmcnt.  Every wave issues the same VMEM operations in every window, branch-free (tail steps re-fetch valid
 //     weights that nobody reads), so the counts are exact.
 //   * ONE s_barrier per step, between k16 steps 2 and 3; fragment reads run one k16 step ahead of their MFMAs.
+//   * Every MFMA gap is written out in the source and fenced (sched_barrier(0)): MFMA, one fragment read, four INDEPENDENT
+//     VALU / transcendental instructions of the staged GroupNorm+SiLU transform, a DMA piece / halo store / hidden load.  At one
+//     wave per SIMD a dependent instruction pair stalls the whole SIMD for its latency: the transform runs as eight stages of
+//     four elements, a stage per gap (round 5; the list scheduler's own order was one serial chain per element).
 //   * MFMA operands swapped (A = weight rows) so an accumulator lane owns 4 consecutive channels of one pixel per
 //     register quad; quads are half-exchanged with v_permlane32_swap so every lane stores 16 bytes.
 #include <stdlib.h>
@@ -250,6 +254,51 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         }
         rh[j] = ((padmask >> j) & 1u) ? zero_chunk<T>() : c;
     };
+    // The same transform as SIXTEEN pieces for the k16 steps of the K loop (one piece per MFMA gap): two half chunks of 4 channels,
+    // each as eight stages of 4 independent instructions -- convert, scale/shift, * -log2 e, exp2, + 1, rcp, * y, pack + zero the
+    // padding.  An instruction and its consumer are then always one MFMA (32 cycles) apart.  The plain loop above compiles to one
+    // serial dependency chain per element (cvt -> fma -> mul -> exp -> add -> rcp -> mul, each waiting for its predecessor's
+    // latency), and at one wave per SIMD nothing else issues while the wave waits: those k16 steps ran at ~2x their MFMA time.
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    float xy[2][4], xt[2][4];                           // two chunks in flight in the prologue (sc = 0 / 1), one in the K loop
+    chunk_t xc[2];
+    auto xform_piece = [&](auto jc, auto mc, auto scc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, m = decltype(mc)::value, h = m >> 3, st = m & 7, sc = decltype(scc)::value;
+        if constexpr (m == 0) { reg_fence(rh[j]); xc[sc] = rh[j]; }
+        if constexpr (st == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xy[sc][e] = to_f32<T>(xc[sc][4 * h + e]);
+        } else if constexpr (st == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xy[sc][e] = __builtin_fmaf(xy[sc][e], ssr[2 * (4 * h + e)], ssr[2 * (4 * h + e) + 1]);
+        } else if constexpr (st == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[sc][e] = xy[sc][e] * -1.44269504088896341f;
+        } else if constexpr (st == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[sc][e] = exp2_fast(xt[sc][e]);
+        } else if constexpr (st == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[sc][e] = xt[sc][e] + 1.0f;
+        } else if constexpr (st == 5) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[sc][e] = __builtin_amdgcn_rcpf(xt[sc][e]);
+        } else if constexpr (st == 6) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xy[sc][e] = xy[sc][e] * xt[sc][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xc[sc][4 * h + e] = from_f32<T>(xy[sc][e]);
+            if constexpr (h == 0) opaque(xc[sc]);      // (keeps the two v_cvt_pk of this half in this gap: they would sink to the chunk's last use)
+            if constexpr (h == 1) {
+                u32x4_t u = __builtin_bit_cast(u32x4_t, xc[sc]);
+                const bool pad = (padmask >> j) & 1u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = pad ? 0u : u[r];
+                rh[j] = __builtin_bit_cast(chunk_t, u);
+            }
+        }
+    };
     auto halo_store = [&](int j) __attribute__((always_inline)) {
         *(chunk_t*)(i2i_smem + (j == HPT - 1 ? st_last : st_off + j * (NT / 8) * 32)) = rh[j];
     };
@@ -289,8 +338,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     wait_vmcnt<0>();
     lds_barrier();
     load_ssr(0);
+    if constexpr (GN) {
+        // two chunks at a time through the staged transform: every stage is 8 independent instructions (the element-by-element
+        // form is a dependent chain of ~9 instructions per element, and nothing else issues on this SIMD while it waits)
+        static_for_w<(HPT + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int j0 = 2 * decltype(pc)::value, j1 = j0 + 1;
+            static_for_w<16>([&](auto mc) __attribute__((always_inline)) {
+                xform_piece(icw<j0>{}, mc, icw<0>{});
+                if constexpr (j1 < HPT) xform_piece(icw<j1>{}, mc, icw<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            halo_store(j0);
+            if constexpr (j1 < HPT) halo_store(j1);
+        });
+    } else {
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
+        for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
+    }
     lds_barrier();
 
     // ---- per-lane LDS read bases.  Pixel fragment row = u + c with u = wm*FM*34 + l31 (lane) and c = (i+dy)*34 + dx
@@ -321,45 +385,47 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     auto nh = [](int t) constexpr { int c = 0; for (int j = t; j < HPT && t >= 0 && t < LW; j += LW) ++c; return c; };
     static_assert(SUBPIX || HPT <= 4 * LW, "halo chunks do not fit the windows of taps 0..5 / the four k16 steps");
 
-    // One k16 step: `pre` (the GroupNorm+SiLU VALU of one parked chunk) is spread over all of its MFMAs; the fragment
-    // reads of the NEXT k16 step go out beside its first MFMAs (weights first: the i-major MFMA order needs every weight
-    // fragment and x[0] at once); `post` (DMA pieces / halo stores: LDS writers, which the scheduler keeps behind the
-    // reads issued before them) one per MFMA after that.
-    auto kstep = [&](auto tapc, auto kkc, auto&& pre, auto has_pre_c, auto&& post, auto npost_c) __attribute__((always_inline)) {
-        constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+    // One k16 step = NMM = 16 MFMAs (i-major over the wave's FM x FN fragments).
+    // jc: icw<j> = the parked chunk this step transforms (GN kernels; -1 = none); post(icw<k>), k < NPO: LDS writers of the step
+    // (DMA pieces, halo stores); wload(icw<k>), k < NWL: the window's hidden loads.  Every MFMA gap is its own scheduling region
+    // (sched_barrier(0)): gap m = MFMA m, fragment read m of the next k16 step (weights first: the i-major MFMA order needs every
+    // weight fragment and x[0] at once), then the post pieces and hidden loads dealt over the gaps without a read, and piece m of
+    // the transform.  (sched_group_barrier pipelines over the whole step left this to the list scheduler's register-pressure
+    // heuristics, which clumped 30 .. 80 instructions in front of single MFMAs in half of the instantiations.)
+    auto kstep = [&](auto tapc, auto kkc, auto jc, auto&& post, auto npost_c, auto&& wload, auto nwl_c) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value, jx = decltype(jc)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
         constexpr bool xnext = kk < 3 || tap < NTAPS - 1;          // not across the slab hand-over
         constexpr int ntap = kk < 3 ? tap : tap + 1, nkk = (kk + 1) & 3;
-        pre();
-        wf[nxt][0] = wread(ntap % RING, 0, nkk);                  // 9 % 3 == 0: the next slab's tap 0 too
-        if constexpr (xnext) xf[nxt][0] = xread(ntap, 0, nkk);
-#pragma unroll
-        for (int j = 1; j < FN; ++j) wf[nxt][j] = wread(ntap % RING, j, nkk);
-        if constexpr (xnext) {
-#pragma unroll
-            for (int i = 1; i < FM; ++i) xf[nxt][i] = xread(ntap, i, nkk);
-        }
-        post();
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
-        constexpr int NRD = FN + (xnext ? FM : 0), NMM = FM * FN, NPO = decltype(npost_c)::value;
-        constexpr bool HP = decltype(has_pre_c)::value && GN;
-        // one transform = 8 x (cvt, fma, mul, exp, add, rcp, mul) + 4 cvt_pk + 4 cndmask: 16 transcendental + ~52 other VALU
-        constexpr int NV = HP ? (52 + NMM - 1) / NMM : 0, NTR = HP ? (16 + NMM - 1) / NMM : 0;
-        static_assert(NRD <= NMM, "");
-#pragma unroll
-        for (int m = 0; m < NMM; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (m - NRD < NPO) __builtin_amdgcn_sched_group_barrier(0x210, 1, 0);    // VMEM | DS write
-            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-            if (NTR > 0) __builtin_amdgcn_sched_group_barrier(0x400, NTR, 0);
-        }
-        if constexpr (NPO > NMM - NRD) __builtin_amdgcn_sched_group_barrier(0x210, NPO - (NMM - NRD), 0);
+        constexpr int NRD = FN + (xnext ? FM : 0), NMM = FM * FN, NPO = decltype(npost_c)::value, NWL = decltype(nwl_c)::value;
+        constexpr bool HP = jx >= 0 && GN;
+        static_assert(NRD < NMM && NMM == 16, "");
+        constexpr int G = NMM - NRD;                              // gaps without a fragment read
+        if constexpr (jx >= 0 && !GN) { reg_fence(rh[jx]); halo_xform(jx); }      // (raw staging: only the padding is zeroed)
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_w<NMM>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value, i = m / FN, j = m % FN;
+            if (!W32_ABL(8)) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+            if constexpr (m < NRD) {
+                // read order: w0, x0, w1 .. w(FN-1), x1 .. x(FM-1)
+                if constexpr (m == 0) wf[nxt][0] = wread(ntap % RING, 0, nkk);
+                else if constexpr (xnext && m == 1) xf[nxt][0] = xread(ntap, 0, nkk);
+                else if constexpr (m < (xnext ? 1 : 0) + FN) wf[nxt][m - (xnext ? 1 : 0)] = wread(ntap % RING, m - (xnext ? 1 : 0), nkk);
+                else xf[nxt][m - FN] = xread(ntap, m - FN, nkk);
+            } else {
+                static_for_w<(NPO + G - 1) / G>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(rc)::value * G + (m - NRD);
+                    if constexpr (k < NPO) post(icw<k>{});
+                });
+                static_for_w<(NWL + G - 1) / G>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(rc)::value * G + (NMM - 1 - m);
+                    if constexpr (k < NWL) wload(icw<k>{});
+                });
+            }
+            if constexpr (HP) xform_piece(icw<jx>{}, mc, icw<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
-    auto none = []() __attribute__((always_inline)) {};
 
     constexpr int DMA_OPS = BPW;
     // RES: the LAST slab has no next halo to stage; its hidden-load slots (same count per window, so every counted wait stays
@@ -386,14 +452,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         constexpr bool LAST = decltype(lastc)::value && NPRE > 0;
         // chunks loaded in window tap-3 landed before P_{tap-1}: transform the q-th beside k16 step q
         // (SUBPIX: four taps per slab and no transform -- the chunks are fenced and their padding zeroed at the store)
-        auto xf_q = [&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value, j = tap - 3 + q * LW;
-            if constexpr (!SUBPIX && !LAST && tap >= 3 && j < HPT) { reg_fence(rh[j]); halo_xform(j); }
-        };
-        auto has_q = [&](int q) constexpr { return !SUBPIX && !LAST && tap >= 3 && tap - 3 + q * LW < HPT; };
-        kstep(tapc, icw<0>{}, [&]() __attribute__((always_inline)) { xf_q(icw<0>{}); }, icw<has_q(0)>{}, none, icw<0>{});
-        kstep(tapc, icw<1>{}, [&]() __attribute__((always_inline)) { xf_q(icw<1>{}); }, icw<has_q(1)>{}, none, icw<0>{});
-        kstep(tapc, icw<2>{}, [&]() __attribute__((always_inline)) { xf_q(icw<2>{}); }, icw<has_q(2)>{}, none, icw<0>{});
+        auto jq = [&](int q) constexpr { return (!SUBPIX && !LAST && tap >= 3 && tap - 3 + q * LW < HPT) ? tap - 3 + q * LW : -1; };
+        auto nonek = [](auto) __attribute__((always_inline)) {};
+        kstep(tapc, icw<0>{}, icw<jq(0)>{}, nonek, icw<0>{}, nonek, icw<0>{});
+        kstep(tapc, icw<1>{}, icw<jq(1)>{}, nonek, icw<0>{}, nonek, icw<0>{});
+        kstep(tapc, icw<2>{}, icw<jq(2)>{}, nonek, icw<0>{}, nonek, icw<0>{});
         __builtin_amdgcn_sched_barrier(0);
         W32_TR(1);
         // -- P_s: publishes B[s+1] (issued after P_{s-2}).  Outstanding VMEM allowed = the window issued after P_{s-1}:
@@ -403,35 +466,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         W32_TR(2);
         lds_barrier();
         W32_TR(3);
-        // -- window after P_s: next slab's halo chunks (hidden loads; from this slab again when there is no next one, the
-        //    count per window never changes), then -- beside the MFMAs of k16 step 3 -- the DMA of B[s+3] into the ring
-        //    slot step s just released and, at tap 8, the stores of the next slab's halo
-        {
-            const int hs = slab + 1 < nslab ? slab + 1 : slab;
-            if constexpr (tap < LW) {
-#pragma unroll
-                for (int j = tap; j < HPT; j += LW) {
-                    if (LAST && j < NPRE * RCH) res_prefetch(j);
-                    else halo_load(hs, j, true);
-                }
-            }
-        }
+        // -- window after P_s, beside the MFMAs of k16 step 3: next slab's halo chunks (hidden loads; from this slab again when
+        //    there is no next one, the count per window never changes), the DMA of B[s+3] into the ring slot step s just released
+        //    and, at tap 8, the stores of the next slab's halo
+        const int hs = slab + 1 < nslab ? slab + 1 : slab;
+        constexpr int NWLD = tap < LW ? nh(tap) : 0;
+        auto wl = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int j = tap + decltype(kc)::value * LW;
+            if constexpr (LAST && j < NPRE * RCH) res_prefetch(j);
+            else halo_load(hs, j, true);
+        };
         constexpr int NST = (tap == NTAPS - 1 && !LAST) ? HPT : 0;
-        kstep(tapc, icw<3>{}, [&]() __attribute__((always_inline)) { xf_q(icw<3>{}); }, icw<has_q(3)>{},
-              [&]() __attribute__((always_inline)) {
-                  if constexpr (tap == NTAPS - 1 && !LAST) {
-#pragma unroll
-                      for (int j = 0; j < HPT; ++j) {
-                          if constexpr (SUBPIX) { reg_fence(rh[j]); halo_xform(j); }
-                          halo_store(j);
-                      }
-                  }
-#pragma unroll
-                  for (int q = 0; q < BPW; ++q) {
-                      if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
-                      else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
-                  }
-              }, icw<NST + BPW>{});
+        auto po = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < NST) {
+                if constexpr (SUBPIX) { reg_fence(rh[k]); halo_xform(k); }
+                halo_store(k);
+            } else {
+                constexpr int q = k - NST;
+                if constexpr (tap + RING < NTAPS) b_dma_q(slab, tap + RING, tap % RING, q);
+                else b_dma_q(slab + 1, tap + RING - NTAPS, tap % RING, q);
+            }
+        };
+        kstep(tapc, icw<3>{}, icw<jq(3)>{}, po, icw<NST + BPW>{}, wl, icw<NWLD>{});
         __builtin_amdgcn_sched_barrier(0);
         W32_TR(4);
     };

@@ -595,7 +595,7 @@ bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.K != p.ks * p.ks * cin || cin % G32_BK || cin < G32_BK || (p.c1 && p.c0 % G32_BK)) return false;
     if (p.lda0 % 8 || (p.a1 && p.lda1 % 8) || p.ldb % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     if (((uintptr_t)p.a0 | (uintptr_t)p.a1 | (uintptr_t)p.b | (uintptr_t)p.c | (uintptr_t)p.res) & 15) return false;
-    if (p.bias_mode == 1 && ((uintptr_t)p.bias & 15)) return false;
+    if (p.bias && (p.geglu || p.bias_mode == 1) && ((uintptr_t)p.bias & 15)) return false;      // (both epilogues read the bias as 16-byte vectors)
     if (p.M < 1 || p.N < 32 || p.N % 8) return false;
     if (p.geglu && (p.N % 32 || p.bias_mode == 2)) return false;
     if (p.gn_part && g32_gn_parts(p, p.gn_part_groups) == 0) return false;

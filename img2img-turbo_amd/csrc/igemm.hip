@@ -39,7 +39,7 @@ int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s);
 namespace {
 // the one routing decision i2i_igemm / i2i_igemm_route / i2i_igemm_gn_parts share for the wide GEMM (tile ids 50..54)
 bool routes_to_gemm_w32(const i2i_igemm_params& p, int dtype) {
-    if (p.tile >= 50 && p.tile <= 59) return i2i::gemm_w32_eligible(p, dtype);
+    if (p.tile >= 50 && p.tile <= 56) return i2i::gemm_w32_eligible(p, dtype);
     return p.tile == 0 && i2i::gemm_w32_auto(p, dtype);
 }
 }  // namespace
@@ -334,7 +334,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..56 = force)
-    if (p.tile >= 50 && p.tile <= 59 && !i2i::gemm_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (wide GEMM) not applicable", p.tile);
+    if (p.tile >= 57 && p.tile <= 59) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d is not a wide-GEMM configuration (50 = auto, 51..56)", p.tile);
+    if (p.tile >= 50 && p.tile <= 56 && !i2i::gemm_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (wide GEMM) not applicable", p.tile);
     if (routes_to_gemm_w32(p, dtype)) return i2i::gemm_w32(p, dtype, s);
     // everything else without a GroupNorm prologue goes through the LDS-DMA engine (tile 0 = auto, 20..29 = force)
     const bool dma_forced = p.tile >= 20 && p.tile <= 29;

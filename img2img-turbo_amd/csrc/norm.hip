@@ -95,24 +95,76 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const i2i_gn_stats_para
 }
 
 // ---- second pass for groups whose one-pass variance cannot be trusted.  E[x^2] - mu^2 in fp32 loses log2(mu^2/var) bits to
-// cancellation on top of the rounding the long sums already carry: with |mean| > 16 sigma the relative error of the variance
-// passes ~1e-3 (F.group_norm is two-pass / Welford; real SD-VAE decoder activations do sit on large DC offsets).  Those
-// groups -- and only those: the decision is a deterministic function of the first pass -- are re-read by the whole block
-// against the first-pass mean: mu' = mu + E[x - mu], var' = E[(x - mu)^2] - E[x - mu]^2, exact to fp32 round-off.  Needs the
-// tensor (p.x0 / p.x1), also in finalize_only mode; without it (x0 == NULL) the one-pass numbers stand.
-constexpr float GN_REFINE_RATIO = 256.f;          // refine when var * 256 < mu^2
+// cancellation on top of the rounding the sums already carry (~1e-6 relative: per-tile partial sums combined in a fixed tree):
+// the relative error of the variance is ~1e-6 * mu^2/var.  F.group_norm is two-pass / Welford, and real SD-VAE decoder
+// activations do sit on large DC offsets.  The flagged groups -- and only those: the decision is a deterministic function of
+// the first pass -- are re-read by the whole block against the first-pass mean: mu' = mu + E[x - mu],
+// var' = E[(x - mu)^2] - E[x - mu]^2, exact to fp32 round-off.  Needs the tensor (p.x0 / p.x1), also in finalize_only mode;
+// without it (x0 == NULL) the one-pass numbers stand.
+//
+// WHEN a group is flagged depends on the storage type, because the consumer only keeps so much: the normalised value is applied
+// to / stored as a `dtype` number, i.e. rounded to 2^-p of its magnitude (p = 8 mantissa bits for bf16, 11 for fp16), while a
+// variance error delta moves a normalised value x^ by |x^| delta / 2 with delta ~ 1e-6 * mu^2 / var (measured 7.8e-3 on outputs
+// up to 5.7 at mu^2 / var = 1e4, 512 conv-epilogue style parts: tests/opcheck.py check_gn_stats_offset).  The second pass is worth
+// its re-read of the tensor only while that error can exceed a rounding step of the consumer: mu^2 / var > ~2^-p / 1e-6 / 2.
+// fp32 storage keeps the round-2 setting (256: well inside north_star's 1e-3); fp16 flags at 2048, bf16 at 16384 -- below these
+// ratios the re-read would polish digits the 16-bit output does not have (the price of a flagged tensor: bench.py
+// --activation-offset).
+template <typename T> struct GnRefine;
+template <> struct GnRefine<float> { static constexpr float RATIO = 256.f; };
+template <> struct GnRefine<_Float16> { static constexpr float RATIO = 2048.f; };
+template <> struct GnRefine<__bf16> { static constexpr float RATIO = 16384.f; };
+// One group = cpg CONSECUTIVE channels of every pixel (2 * cpg bytes for the 16-bit types).  A thread takes whole pixels and
+// reads the group's channels in the widest pieces the group's first channel allows (16 / 8 / 4 bytes: cpg = 16 / 8 / 4 for the
+// VAE's 512 / 256 / 128-channel planes, 4-byte pieces for the UNet's 10 / 20 / 40-channel groups), four pixels in flight per trip
+// (a lone dependent stream of loads is latency bound).  Fixed order -> deterministic.
+template <typename T, int VB /* bytes per piece */>
+__device__ __forceinline__ void gn_refine_span(const char* base, int64_t ldb, int hw, int nbytes, float mu, float& s1, float& s2) {
+    constexpr int EPV = VB / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(EPV)));
+    const int npc = nbytes / VB;
+    constexpr int UNR = 4;
+    for (int px0 = threadIdx.x; px0 < hw; px0 += 256 * UNR) {
+        for (int k = 0; k < npc; ++k) {
+            vec_t v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int px = px0 + u * 256;
+                v[u] = *(const vec_t*)(base + (int64_t)(px < hw ? px : px0) * ldb + k * VB);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (px0 + u * 256 < hw) {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const float d = to_f32<T>(v[u][e]) - mu;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                }
+            }
+        }
+    }
+}
 template <typename T>
 __device__ void gn_refine_group(const i2i_gn_stats_params& p, int img, int g, float* red /* >= 512 floats of LDS */, float& mu, float& var) {
     const int tid = threadIdx.x, ct = p.c0 + p.c1, cpg = ct / p.groups;
     float s1 = 0.f, s2 = 0.f;
-    for (int px = tid; px < p.hw; px += 256)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const T* src = (c < p.c0) ? (const T*)p.x0 + ((int64_t)img * p.hw + px) * p.ld0 + c
-                                      : (const T*)p.x1 + ((int64_t)img * p.hw + px) * p.ld1 + (c - p.c0);
-            const float d = to_f32<T>(*src) - mu;
-            s1 += d;
-            s2 += d * d;
-        }
+    // the group's channels inside each source: [ca, cb) of x0 and [cc, cd) of x1 (a group may straddle the concat boundary)
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    for (int src = 0; src < 2; ++src) {
+        const int lo = src == 0 ? c_lo : (c_lo > p.c0 ? c_lo : p.c0), hi = src == 0 ? (c_hi < p.c0 ? c_hi : p.c0) : c_hi;
+        if (hi <= lo || (src == 1 && !p.x1)) continue;
+        const int ld = src == 0 ? p.ld0 : p.ld1, c_in = src == 0 ? lo : lo - p.c0;
+        const char* base = (const char*)((const T*)(src == 0 ? p.x0 : p.x1) + (int64_t)img * p.hw * ld + c_in);
+        const int nbytes = (hi - lo) * (int)sizeof(T);
+        const int64_t ldb = (int64_t)ld * (int)sizeof(T);
+        const int al = (int)(((uintptr_t)base | (uintptr_t)ldb | (uintptr_t)nbytes) & 15);
+        if (al == 0) gn_refine_span<T, 16>(base, ldb, p.hw, nbytes, mu, s1, s2);
+        else if ((al & 7) == 0) gn_refine_span<T, 8>(base, ldb, p.hw, nbytes, mu, s1, s2);
+        else if ((al & 3) == 0) gn_refine_span<T, 4>(base, ldb, p.hw, nbytes, mu, s1, s2);
+        else gn_refine_span<T, (int)sizeof(T)>(base, ldb, p.hw, nbytes, mu, s1, s2);
+    }
     __syncthreads();
     red[2 * tid] = s1;
     red[2 * tid + 1] = s2;
@@ -162,7 +214,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
     __syncthreads();
     for (int g = 0; g < gpb; ++g) {                // uniform over the block
         float mu = mean[g], var = rstd[g];
-        if (p.x0 && var * GN_REFINE_RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
+        if (p.x0 && var * GnRefine<T>::RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
         __syncthreads();
         if (tid == 0) { mean[g] = mu; rstd[g] = rsqrtf(var + p.eps); }
     }
@@ -345,7 +397,133 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
     __syncthreads();
     for (int g = 0; g < gpb; ++g) {                // uniform over the block
         float mu = gst[2 * g], var = gst[2 * g + 1];
-        if (var * GN_REFINE_RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
+        if (var * GnRefine<T>::RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
+        __syncthreads();
+        if (tid == 0) { gst[2 * g] = mu; gst[2 * g + 1] = rsqrtf(var + p.eps); }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {
+        const int g = c / cpg, cc = c_first + c;
+        const float sc = gst[2 * g + 1] * p.gamma[cc];
+        float* o = p.ss + ((int64_t)img * ct + cc) * 2;
+        o[0] = sc;
+        o[1] = p.beta[cc] - gst[2 * g] * sc;
+    }
+}
+
+// ---- the same, with every image's pixels cut into S slices (grid z): at batch 1 the kernel above runs on 8 workgroups (32 groups
+// in sets of 4) and each of them streams 300+ KB through 256 threads -- 13.8 us per launch, 63 launches per forward.  Slice
+// workgroup (img, set, s) reduces its pixels to (sum, sum of squares) per group and publishes the gpb pairs with 8-byte
+// agent-scope stores (write-through: visible to every XCD once the store is acknowledged -- no release fence, whose L2 write-back
+// costs more than this whole kernel), waits for them (vmcnt 0), and draws a ticket from the (img, set) counter; the workgroup that
+// draws S-1 reads all S slices back with agent-scope loads, adds them IN SLICE ORDER (deterministic whichever workgroup is
+// last), finalises as above and re-zeroes the counter for the next launch.  (cdna_hip_programming.md section 6, Guideline 16:
+// "8-B agent atomics both sides" hand-off; the ticket is a relaxed agent-scope fetch_add.)
+#ifdef I2I_EMU
+__device__ __forceinline__ void gn_publish(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
+__device__ __forceinline__ void gn_fetch(const float* src, float& a, float& b) { a = src[0]; b = src[1]; }
+__device__ __forceinline__ int gn_ticket(int32_t* c) { const int v = *c; *c = v + 1; return v; }
+__device__ __forceinline__ void gn_ticket_reset(int32_t* c) { *c = 0; }
+__device__ __forceinline__ void gn_stores_done() {}
+#else
+__device__ __forceinline__ void gn_publish(float* dst, float a, float b) {
+    const unsigned long long v = ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, a);
+    __hip_atomic_store((unsigned long long*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gn_fetch(const float* src, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __builtin_bit_cast(float, (unsigned)v);
+    b = __builtin_bit_cast(float, (unsigned)(v >> 32));
+}
+__device__ __forceinline__ int gn_ticket(int32_t* c) { return __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gn_ticket_reset(int32_t* c) { __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gn_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_sliced_kernel(const i2i_gn_stats_params p, int gpb, int S) {
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int EPC = Elem<T>::EPC;
+    const int tid = threadIdx.x, img = blockIdx.x, set = blockIdx.y, sl = blockIdx.z, g0 = set * gpb;
+    const int ct = p.c0 + p.c1, cpg = ct / p.groups, nsets = p.groups / gpb;
+    const int nch = gpb * cpg, c_first = g0 * cpg;
+    const int U = nch >> 3, ppb = 256 / U;
+    const int unit = tid % U, prow = tid / U;
+    const int per = (p.hw + S - 1) / S, px_lo = sl * per, px_hi = px_lo + per < p.hw ? px_lo + per : p.hw;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (prow < ppb) {
+        const int c = c_first + unit * 8;
+        const T* src = (c < p.c0) ? (const T*)p.x0 + (int64_t)img * p.hw * p.ld0 + c
+                                  : (const T*)p.x1 + (int64_t)img * p.hw * p.ld1 + (c - p.c0);
+        const int ld = (c < p.c0) ? p.ld0 : p.ld1;
+        constexpr int UNR = 4;
+        for (int px0 = px_lo + prow; px0 < px_hi; px0 += ppb * UNR) {
+            chunk_t v[UNR][8 / EPC];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int px = px0 + u * ppb;
+#pragma unroll
+                for (int h = 0; h < 8 / EPC; ++h)
+                    v[u][h] = (px < px_hi) ? *(const chunk_t*)(src + (int64_t)px * ld + h * EPC) : zero_chunk<T>();
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int h = 0; h < 8 / EPC; ++h)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float f = to_f32<T>(v[u][h][e]);
+                        s[h * EPC + e] += f;
+                        q[h * EPC + e] += f * f;
+                    }
+        }
+    }
+    float* red = (float*)i2i_smem;                // [256][16]
+    float* chs = red + 256 * 16;                  // [nch][2]
+    float* gst = chs + 2 * nch;                   // [gpb][2] mean, rstd
+    int* flag = (int*)(gst + 2 * gpb);            // the ticket this workgroup drew
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {        // per-channel totals over the pixel rows, fixed order
+        const int u = c >> 3, e = c & 7;
+        float S1 = 0.f, Q1 = 0.f;
+        for (int r = 0; r < ppb; ++r) { S1 += red[(r * U + u) * 16 + e]; Q1 += red[(r * U + u) * 16 + 8 + e]; }
+        chs[2 * c] = S1; chs[2 * c + 1] = Q1;
+    }
+    __syncthreads();
+    float* slot = p.partial + ((((int64_t)img * nsets + set) * S) * gpb) * 2;      // [S][gpb][2] of this (image, group set)
+    if (tid < gpb) {
+        float S1 = 0.f, Q1 = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { S1 += chs[2 * c]; Q1 += chs[2 * c + 1]; }
+        gn_publish(slot + ((int64_t)sl * gpb + tid) * 2, S1, Q1);
+    }
+    gn_stores_done();
+    __syncthreads();
+    if (tid == 0) *flag = gn_ticket(p.counters + img * nsets + set);
+    __syncthreads();
+    if (*flag != S - 1) return;                   // (uniform over the workgroup)
+    // all S * gpb pairs in flight at once (one per thread: a dependent chain of L2 round trips otherwise), then summed in slice order
+    for (int t = tid; t < S * gpb; t += 256) {
+        float a, b;
+        gn_fetch(slot + (int64_t)t * 2, a, b);
+        if (t < 2048) { red[2 * t] = a; red[2 * t + 1] = b; }
+    }
+    __syncthreads();
+    if (tid < gpb) {
+        float S1 = 0.f, Q1 = 0.f;
+        for (int k = 0; k < S; ++k) { S1 += red[(k * gpb + tid) * 2]; Q1 += red[(k * gpb + tid) * 2 + 1]; }
+        const float inv = 1.0f / ((float)cpg * (float)p.hw);
+        const float mu = S1 * inv;
+        gst[2 * tid] = mu;
+        gst[2 * tid + 1] = fmaxf(Q1 * inv - mu * mu, 0.f);   // variance for now: the refinement below may replace it
+    }
+    if (tid == 0) gn_ticket_reset(p.counters + img * nsets + set);
+    __syncthreads();
+    for (int g = 0; g < gpb; ++g) {                // uniform over the block
+        float mu = gst[2 * g], var = gst[2 * g + 1];
+        if (var * GnRefine<T>::RATIO < mu * mu) gn_refine_group<T>(p, img, g0 + g, red, mu, var);
         __syncthreads();
         if (tid == 0) { gst[2 * g] = mu; gst[2 * g + 1] = rsqrtf(var + p.eps); }
     }
@@ -415,7 +593,20 @@ int gn_stats_t(const i2i_gn_stats_params& p, hipStream_t s) {
         for (int cand = 4; cand <= 16 && !gpb; cand <<= 1)      // fewest groups per block whose channels form whole 8-channel units
             if (p.groups % cand == 0 && (cand * cpg) % 8 == 0 && (cand * cpg) / 8 <= 256) gpb = cand;                 // (a block may straddle the two sources: every 8-channel unit picks its own)
         if (!p.finalize_only && gpb && (int64_t)p.hw * ct0 <= (3 << 20)) {
-            const size_t smem = (256 * 16 + 2 * gpb * cpg + 2 * gpb) * sizeof(float);
+            const size_t smem = (256 * 16 + 2 * gpb * cpg + 2 * gpb + 4) * sizeof(float);
+            // pixel slices (needs the ticket counters): as many as `partial` has room for, about 1024 workgroups per launch,
+            // at least 64 pixels each
+            if (p.counters) {
+                const int nsets = p.groups / gpb;
+                int S = 1024 / (p.nimg * nsets);
+                S = S < p.nparts ? S : p.nparts;
+                S = S < p.hw / 64 ? S : p.hw / 64;
+                S = S < 2048 / gpb ? S : 2048 / gpb;      // (the last workgroup stages all pairs in its 16 KiB reduction array)
+                if (S > 1) {
+                    hipLaunchKernelGGL((gn_stats_sliced_kernel<T>), dim3((unsigned)p.nimg, (unsigned)nsets, (unsigned)S), dim3(256), smem, s, p, gpb, S);
+                    return i2i::check_launch("gn_stats_sliced");
+                }
+            }
             hipLaunchKernelGGL((gn_stats_small_kernel<T>), dim3((unsigned)p.nimg, (unsigned)(p.groups / gpb)), dim3(256), smem, s, p, gpb);
             return i2i::check_launch("gn_stats_small");
         }

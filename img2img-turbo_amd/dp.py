@@ -50,7 +50,12 @@ class OutputGather:
     device copy of a few MB), and the collective runs on a side stream behind an event -- the compute stream goes straight on
     to the replay of step i+1 while RCCL moves step i over xGMI.  Buffer i % 2 (and its slab on ``dst``) is reused at step
     i+2, after the compute stream has waited for the gather of step i.  ``images()`` / ``wait()`` join the side stream.
-    On CPU tensors (gloo, the tests) there are no streams: same buffers, same alternation, synchronous collectives."""
+    On CPU tensors (gloo, the tests) there are no streams: same buffers, same alternation, synchronous collectives.
+
+    Ownership in overlap mode: the slabs belong to the gather -- the side stream overwrites slab i % 2 two steps later, ordered
+    only against the compute stream.  ``__call__`` therefore hands out no slab (returns None) and ``images()`` returns a COPY
+    made on the current stream after joining the side stream; the copy is stream-ordered before the next staging copy, whose
+    event the gather of step i+2 waits for, so that gather cannot overtake a reader of the returned tensor on this stream."""
 
     def __init__(self, local, total, dst=0, overlap=False):
         self.local, self.total, self.dst, self.overlap = local, total, dst, overlap
@@ -80,8 +85,9 @@ class OutputGather:
         return None if self.slabs is None else self.slabs[(self.step - 1) % len(self.slabs)]
 
     def __call__(self):
-        """-> on ``dst``: the slab [world, max_shard, ...] this step gathers into (rank r's images are slab[r, :sizes[r]];
-        with overlap=True it is complete only after wait() / images()); None elsewhere."""
+        """overlap=False -> on ``dst``: the slab [world, max_shard, ...] of this step, complete on return (rank r's images are
+        slab[r, :sizes[r]]); None elsewhere.  overlap=True -> None everywhere: the slab is still being written by the side stream
+        and will be overwritten two steps later -- read the step through ``images()``."""
         i = self.step % len(self.send)
         self.step += 1
         send = self.send[i]
@@ -90,7 +96,7 @@ class OutputGather:
             if send is not self.local:
                 send[: self.local.shape[0]].copy_(self.local)
             dist.gather(send, views, dst=self.dst)
-            return self.slabs[i] if self.slabs is not None else None
+            return self.slabs[i] if (self.slabs is not None and not self.overlap) else None
         cur = torch.cuda.current_stream(self.local.device)
         if self.gathered[i] is not None:
             cur.wait_event(self.gathered[i])            # the gather of step i-2 has read this staging buffer
@@ -102,7 +108,7 @@ class OutputGather:
             ev = torch.cuda.Event()
             ev.record(self.comm)
             self.gathered[i] = ev
-        return self.slabs[i] if self.slabs is not None else None
+        return None
 
     def wait(self):
         """Join the side stream: everything gathered so far is complete for the current stream."""
@@ -110,13 +116,15 @@ class OutputGather:
             torch.cuda.current_stream(self.local.device).wait_stream(self.comm)
 
     def images(self):
-        """[total, ...] on ``dst`` in global batch order, of the most recent step (a copy only when shards are ragged)."""
+        """[total, ...] on ``dst`` in global batch order, of the most recent step.  overlap=False: a view of the slab when the
+        shards are even (a copy when ragged); overlap=True: always a copy (the slab is reused two steps later)."""
         self.wait()
         if self.rank != self.dst:
             return None
         slab = self.slab
         if len(set(self.sizes)) == 1:
-            return slab.reshape((self.total,) + tuple(slab.shape[2:]))
+            out = slab.reshape((self.total,) + tuple(slab.shape[2:]))
+            return out.clone() if self.overlap else out
         return torch.cat([slab[r, :s] for r, s in enumerate(self.sizes)], dim=0)
 
 

@@ -79,8 +79,9 @@ def bgemm(a, b, out, *, M, N, Kdim, lda, ldb, ldc, batch, heads, a_bs, b_bs, c_b
 
 
 def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=None, c0=None, c1=0,
-             ld0=None, ld1=None, finalize_only=0):
+             ld0=None, ld1=None, finalize_only=0, counters=None):
     p = K.GnStatsParams()
+    p.counters = ptr(counters)
     p.x0, p.x1 = ptr(x0), ptr(x1)
     p.finalize_only = finalize_only
     p.c0 = x0.shape[-1] if c0 is None else c0

@@ -101,11 +101,13 @@ class ForwardPlan:
         self.op_flops = []      # algorithmic FLOPs per op (2*MAC), parallel to prog.ops
         self.op_flops_exec = [] # FLOPs the matrix pipe executes for the op (sub-pixel upsamplers: 4/9 of the 3x3 part), parallel to prog.ops
         self.op_kernel = []     # HIP kernel each op resolves to (reporting only), parallel to prog.ops
+        self.op_bytes = []      # algorithmic HBM bytes per op for the HBM-bound kernels (1 read [+ 1 write] per element), parallel to prog.ops
         self.flops = 0
         self.gn_partial = None
         self.gn_ss = None
         self._gn_part_elems = 0
         self._gn_ss_elems = 0
+        self._gn_cnt_elems = 0
         self._pending_gn = []
         self._keep = []         # tensors referenced by the program that are not owned by the pool
         self._ckv = None        # merged cross-attention K / V^T of the UNet (see _cross_kv)
@@ -144,13 +146,14 @@ class ForwardPlan:
         self.graph = None
 
     # ------------------------------------------------------------------ helpers
-    def _add(self, op, label, flops=0, kernel=None, flops_exec=None):
+    def _add(self, op, label, flops=0, kernel=None, flops_exec=None, nbytes=0):
         """Record one launch.  ``kernel``: which HIP kernel the C dispatcher will pick for an igemm op (i2i_igemm_route),
         used only for reporting (bench.py groups timings by kernel).  ``flops``: algorithmic FLOPs of the reference op(s)
         the launch replaces; ``flops_exec``: what the matrix pipe executes when that differs (sub-pixel upsamplers)."""
         self.prog.add(op[0], self.dt, op[1], label)
         self.op_flops.append(flops)
         self.op_flops_exec.append(flops if flops_exec is None else flops_exec)
+        self.op_bytes.append(nbytes)       # algorithmic HBM bytes of the HBM-bound launches (norms, layout / latent ops); 0 = not priced
         self.op_kernel.append(kernel or {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax",
                                         K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply",
                                         K.OP_IGEMM: "igemm_dma_kernel"}.get(op[0], "boundary/elementwise"))
@@ -161,6 +164,10 @@ class ForwardPlan:
             if p is params:
                 self.op_kernel[i] = kernel
 
+    @property
+    def esz(self):
+        return 4 if self.dtype == torch.float32 else 2
+
     def new(self, n, h, w, c, dtype=None):
         t = self.pool.get(n * h * w * c, dtype or self.dtype)
         return Act(t, n, h, w, c)
@@ -170,14 +177,20 @@ class ForwardPlan:
 
     def _gn_scratch(self, nimg, ct, nparts, groups):
         self._gn_part_elems = max(self._gn_part_elems, nimg * nparts * groups * 2)
+        self._gn_cnt_elems = max(self._gn_cnt_elems, nimg * groups)
         self._gn_ss_elems = max(self._gn_ss_elems, nimg * ct * 2)
 
     def _finish_gn_scratch(self):
         self.gn_partial = torch.zeros(max(self._gn_part_elems, 1), dtype=torch.float32, device=self.device)
         self.gn_ss = torch.zeros(max(self._gn_ss_elems, 1), dtype=torch.float32, device=self.device)
+        # ticket counters of the sliced single-launch statistics kernel (csrc/norm.hip: zero before the first launch, every launch
+        # leaves them zero); I2I_GN_SLICED=0 keeps one workgroup per (image, group set) (A/B hook)
+        self.gn_counters = torch.zeros(max(self._gn_cnt_elems, 1), dtype=torch.int32, device=self.device)
+        sliced = os.environ.get("I2I_GN_SLICED", "1") != "0"
         for p, which in self._pending_gn:   # patch pointers now that the scratch exists
             if which == "stats":
                 p.partial, p.ss = self.gn_partial.data_ptr(), self.gn_ss.data_ptr()
+                p.counters = self.gn_counters.data_ptr() if sliced else 0
             elif which == "stats_ss":
                 p.ss = self.gn_ss.data_ptr()
             elif which == "igemm":
@@ -202,6 +215,19 @@ class ForwardPlan:
                 else:
                     self._reroute(x.producer, "igemm_dma_kernel")
             if parts > 0:
+                # The slab below is sized for the route seen NOW.  tile == 0 re-resolves the route at every launch (the wide GEMM's
+                # auto rule reads I2I_GEMM_W32 per call) and another kernel would write a different number of slots: name the
+                # route in the op itself, so that an eager run()/run_timed() after an environment change cannot diverge from it.
+                if x.producer.tile == 0:
+                    route = self.lib.igemm_route(x.producer, self.dt)
+                    pin = {"conv3x3_w32_kernel": 40, "conv3x3_w32_kernel<SUBPIX>": 40, "conv3x3_halo_kernel": 10,
+                           "conv3x3_halo_kernel<SUBPIX>": 10, "igemm_dma_kernel": 20}.get(route, 0)
+                    if route == "gemm_w32_kernel":      # statistics come from its 128-column tiles only: 256 rows (53) or 128 rows (54)
+                        pin = 53 if parts * 256 == x.hw else 54
+                    if pin:
+                        x.producer.tile = pin
+                        if self.lib.igemm_route(x.producer, self.dt) != route or self.lib.igemm_gn_parts(x.producer, self.dt, groups) != parts:
+                            x.producer.tile = 0         # (cannot name it: keep the auto route; graph replays are unaffected)
                 # dedicated slab (not pooled): it is written by an op recorded EARLIER than this point, so a pooled
                 # buffer could have been lent to an op in between
                 part = torch.empty(x.n * parts * groups * 2, dtype=torch.float32, device=self.device)
@@ -212,14 +238,20 @@ class ForwardPlan:
                 op = O.gn_stats(x.t, gamma, beta, part, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=parts,
                                 c0=x.c, ld0=x.c, finalize_only=1)
                 self._pending_gn.append((op[1], "stats_ss"))
-                self._add(op, (label or norm_name) + ".finalize")
+                self._add(op, (label or norm_name) + ".finalize", nbytes=x.n * parts * groups * 8 + x.n * ct * 8)
                 return
         nparts = int(min(256, max(1, (x.hw * ct) // 65536)))
         self._gn_scratch(x.n, ct, nparts, groups)
         op = O.gn_stats(x.t, gamma, beta, None, None, nimg=x.n, hw=x.hw, groups=groups, eps=eps, nparts=nparts,
                         x1=x1.t if x1 else None, c0=x.c, c1=x1.c if x1 else 0, ld0=x.c, ld1=x1.c if x1 else 0)
         self._pending_gn.append((op[1], "stats"))
-        self._add(op, label or norm_name)
+        self._add(op, label or norm_name, nbytes=x.n * x.hw * ct * self.esz + x.n * ct * 8)
+
+    def gn_probe_ws(self, numel):
+        """A 16-byte aligned fp32 slab for a route QUERY (never launched): taken from the pool and handed straight back."""
+        t = self.pool.get(numel, torch.float32)
+        self.pool.put(t)
+        return t
 
     def _splitk(self, M, N, Kd):
         """Split-K factor + fp32 slab for the weight-streaming shapes (few rows, K in the thousands); mirrors the
@@ -316,6 +348,22 @@ class ForwardPlan:
                 # the UNet's 32 x 32 / 64 x 64 planes (320 / 640 output channels: 2.5 / 5 halo channel tiles, 650 - 750 TFLOP/s) on
                 # 256 x 160 / 128 x 160 wide-GEMM tiles: 930 - 1115 TFLOP/s before the extra gn_apply pass (profiles/r4k_*)
                 halo, force_tile, grp = False, 20, 8
+        M, N, Kd = x.n * ho * wo, pw["n"], ks * ks * (x.c + c1)
+        if grp in (2, 8):
+            # These two groups leave a conv the halo kernel would take (with GroupNorm fused into its staging) for a wide-GEMM
+            # route that needs the norm materialised: ask the C dispatcher about exactly that op BEFORE recording the extra
+            # gn_apply pass, and keep the halo decision when it says no (wide_ok restates only part of gemm_w32_eligible).
+            cfg_, sk_ = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs)
+            ok_ = bool(cfg_) and M >= self.w32_splitk_min_rows and x.c % epc == 0 and c1 % epc == 0
+            if ok_:
+                ct_ = x.c + c1
+                probe = O.conv(x.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
+                               c0=ct_, c1=0, lda0=ct_, lda1=0, N=pw["n"], bias=pw["b"], alpha=alpha, res=res.t if res else None,
+                               ldr=res.c if res else None, ldc=out.c, splitk=sk_ if sk_ > 1 else 0, ws=self.gn_probe_ws(sk_ * M * N) if sk_ > 1 else None,
+                               tile=cfg_)
+                ok_ = self.lib.igemm_route(probe[1], self.dt) == "gemm_w32_kernel"
+            if not ok_:
+                halo, force_tile, grp = True, 0, 0
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
         if gn and not fused:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
@@ -327,9 +375,8 @@ class ForwardPlan:
                     continue
                 op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
                 self._pending_gn.append((op[1], "apply"))
-                self._add(op, label + ".gn_apply")
+                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
-        M, N, Kd = x.n * ho * wo, pw["n"], ks * ks * (x.c + c1)
         splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
         mk = lambda tile_, splitk_, ws_: O.conv(
             x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
@@ -352,7 +399,9 @@ class ForwardPlan:
                         self.pool.put(ws)
                     op, ws = cand, ws2
                 else:
-                    assert grp not in (2, 8), (label, "taken from the halo conv for a wide-GEMM route that does not exist")
+                    if grp in (2, 8):       # (the probe above asked the same question: unreachable unless the two drift apart)
+                        raise K.I2IError("plan: %s was taken from the halo conv for a wide-GEMM route the dispatcher refuses (%s)"
+                                         % (label, self.lib.igemm_route(cand[1], self.dt)))
                     if ws2 is not None:
                         self.pool.put(ws2)
         if op is None:
@@ -454,7 +503,7 @@ class ForwardPlan:
         xn = self.new(x.n, x.h, x.w, C)
         op = O.gn_apply(x.t, xn.t, None, nimg=B, hw=T, c=C, act=0)
         self._pending_gn.append((op[1], "apply"))
-        self._add(op, prefix + ".gn_apply")
+        self._add(op, prefix + ".gn_apply", nbytes=2 * B * T * C * self.esz)
         qk = self.linear(pk.stacked_linear([prefix + ".to_q", prefix + ".to_k"]), xn.t, B * T, C, label=prefix + ".to_qk")
         wv = pk.conv(prefix + ".to_v")
         Tp = (T + 7) // 8 * 8                      # row pitch of V^T / scores / probabilities (T itself when the plane is /8-aligned)
@@ -629,7 +678,7 @@ class ForwardPlan:
         def ln(name, src):
             g, b = pk.norm(name)
             y = self.pool.get(rows * C, self.dtype)
-            self._add(O.layernorm(src, y, g, b, rows=rows, c=C, eps=1e-5), name)
+            self._add(O.layernorm(src, y, g, b, rows=rows, c=C, eps=1e-5), name, nbytes=2 * rows * C * self.esz)
             return y
 
         y = ln(t + ".norm1", h)
@@ -775,7 +824,8 @@ class ForwardPlan:
         self._zero_init = []
         x = self.new(B, H, W, 8)
         mul, add, thr = (tuple(self.u8_io) + (0,))[:3] if self.u8_io else (1.0, 0.0, 0)      # (mul, add[, binarize_below])
-        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8, mul=mul, add=add, binarize_below=thr), "input.to_nhwc")
+        self._add(O.nchw_to_nhwc(self.x_in, x.t, n=B, c=3, h=H, w=W, cpad=8, mul=mul, add=add, binarize_below=thr), "input.to_nhwc",
+                  nbytes=B * H * W * (3 * self.x_in.element_size() + 8 * self.esz))
         moments, skips = self._vae_encoder(x)
         # x (= conv_in input) is not a skip; skips[0] is conv_in's output
         self.free(x)
@@ -796,7 +846,8 @@ class ForwardPlan:
         self.free(e)
         y = self._vae_decoder(z, skips)
         self.free(z)
-        self._add(O.nhwc_to_nchw(y.t, self.out, n=B, c=3, h=H, w=W, ldx=y.c, clamp=1, mul=0.5, add=0.5), "output.from_nhwc")
+        self._add(O.nhwc_to_nchw(y.t, self.out, n=B, c=3, h=H, w=W, ldx=y.c, clamp=1, mul=0.5, add=0.5), "output.from_nhwc",
+                  nbytes=B * H * W * (y.c * self.esz + 3 * self.out.element_size()))
         for t in self._zero_init:
             t.zero_()
 

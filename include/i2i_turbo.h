@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 6
+#define I2I_ABI_VERSION 7
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -132,6 +132,10 @@ typedef struct {
     int32_t finalize_only;                    /* 1: `partial` was produced by a conv epilogue (gn_part).  x0 (+ ld0) may still be
                                                  given: groups whose one-pass variance is below mean^2 / 256 (cancellation) are
                                                  then re-read against the first-pass mean; with x0 = NULL the one-pass numbers stand */
+    int32_t* counters;                        /* optional (ABI v7), >= nimg*groups ints, ZERO before the first launch (the kernel leaves
+                                                 them zero): lets the single-launch path for small tensors cut every image's pixels
+                                                 into up to `nparts` slices, one workgroup each; the workgroup that arrives last at
+                                                 its (image, group set) ticket sums the slices in a fixed order and writes `ss` */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its

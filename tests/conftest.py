@@ -44,6 +44,12 @@ def gpu_lib():
     import torch
     from img2img_turbo_amd import _capi
     assert torch.cuda.is_available(), "gpu-marked test without a GPU"
+    # host threads for the CPU oracle / the packers: the GPU boxes have hundreds of hardware threads, on which torch's default
+    # (one OpenMP thread each) is far slower than a few dozen for these convolution shapes (bench.py: 16 threads ~10 s per
+    # 512x512 oracle forward).  I2I_TEST_THREADS=0 keeps torch's default.
+    nthr = int(os.environ.get("I2I_TEST_THREADS", "32"))
+    if nthr > 0:
+        torch.set_num_threads(min(nthr, os.cpu_count() or nthr))
     lib = _capi.default_library()
     assert lib.backend == "gfx950"
     # the -m gpu suite certifies the PRODUCT library: an I2I_LIB override (measurement builds) must not ride along silently

@@ -17,6 +17,7 @@ benchmarked batch and the CPU oracle on a SUBSET of the images (first and last),
 import json
 import math
 import os
+import time
 
 import pytest
 import torch
@@ -69,14 +70,18 @@ def sd_weights(kind, **kw):
         while len(_WEIGHTS) >= 4:
             _WEIGHTS.pop(next(iter(_WEIGHTS)))
         make = make_cyclegan_weights if kind == "cyclegan" else make_pix2pix_weights
+        t0 = time.perf_counter()
         _WEIGHTS[key] = make(SD_TURBO_UNET, SD_TURBO_VAE, **kw)
+        print(f"[phase] SD-Turbo-size synthetic weights {key}: {time.perf_counter() - t0:.1f} s")
     return _WEIGHTS[key]
 
 
 def oracle_cached(key, fn):
     """(image, intermediates) of the fp32 oracle for one configuration's fixed weights and inputs, computed once per session."""
     if key not in _ORACLE:
+        t0 = time.perf_counter()
         _ORACLE[key] = fn()
+        print(f"[phase] CPU oracle {key}: {time.perf_counter() - t0:.1f} s ({torch.get_num_threads()} threads)")
     return _ORACLE[key]
 
 
@@ -182,7 +187,7 @@ def test_sd_turbo_odd_size_264x328(gpu_lib):
     33x41 -> 17x21 -> 9x11 -> 5x6, upsampled back with explicit sizes."""
     mw = sd_weights("pix2pix", seed=1234 + 1)
     x, cap, eps, _ = make_inputs("canny", 1, 264, 328, SD_TURBO_UNET.cross_attention_dim, seed=1)
-    ref = pix2pix_forward(mw, x, cap, eps)
+    ref = oracle_cached("odd_264x328", lambda: pix2pix_forward(mw, x, cap, eps))
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
     out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
     assert report("SD-Turbo 264x328 fp32", out, ref) < 1e-3
@@ -198,7 +203,7 @@ def test_full_sd_turbo_512(gpu_lib):
     512x512 image, CPU oracle fp32 vs exact-f32 MFMA (<= 1e-3) and vs bf16 (measured)."""
     mw = sd_weights("pix2pix", seed=1234 + 1)
     x, cap, eps, _ = make_inputs("canny", 1, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=1)
-    ref = pix2pix_forward(mw, x, cap, eps)
+    ref = oracle_cached("full512", lambda: pix2pix_forward(mw, x, cap, eps))
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
     out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
     e32 = report("SD-Turbo 512x512 fp32", out, ref)
@@ -228,9 +233,12 @@ def test_cfg2_pix2pix_bf16_bs8_512(gpu_lib):
     mw = sd_weights("pix2pix", seed=1234 + 2)
     x, cap, eps, _ = make_inputs("canny", 8, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=2)
     x[5], eps[5] = x[0], eps[0]
-    ref = pix2pix_forward(mw, x[[0, 7]], cap, eps[[0, 7]])
+    ref = oracle_cached("cfg2", lambda: pix2pix_forward(mw, x[[0, 7]], cap, eps[[0, 7]]))
+    t0 = time.perf_counter()
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
     out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    torch.cuda.synchronize()
+    print(f"[phase] cfg2 model build + pack + plan + first forward (bf16): {time.perf_counter() - t0:.1f} s")
     check_floor("cfg2 pix2pix bf16 bs=8 512x512 (images 0,7)", out[[0, 7]], ref, "cfg2_pix2pix_bf16_bs8_512")
     assert torch.equal(out[0], out[5]), "same image in another batch slot must give the same bits"
     _free(model)
@@ -251,7 +259,7 @@ def test_decoder_skip_convs_folded_into_the_upsamplers(gpu_lib, monkeypatch):
     device), and sits as close to the oracle as the program with separate skip convs (one rounding fewer)."""
     mw = sd_weights("pix2pix", seed=1234 + 9, sketch=True)
     x, cap, eps, nm = make_inputs("sketch", 8, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=9)
-    ref = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.6, noise_map=nm[:1])
+    ref = oracle_cached("skipfold", lambda: pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.6, noise_map=nm[:1]))
     errs, nops = {}, {}
     for flag in ("1", "0"):
         monkeypatch.setenv("I2I_FUSE_SKIP", flag)
@@ -293,7 +301,7 @@ def test_cfg4_stochastic_bf16_bs16_512(gpu_lib):
                                                         return_intermediates=True))[0]
     out = model(xs, caption_enc=cap.cuda(), eps=es, deterministic=False, r=0.4, noise_map=ns)
     check_floor("cfg4 stochastic r=0.4 bf16 bs=16 (images 0,15)", out[[0, 15]], ref, "cfg4_stochastic_r0.4_bf16_bs16_512")
-    ref1 = pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.8, noise_map=nm[:1])
+    ref1 = oracle_cached("cfg4_r0.8", lambda: pix2pix_forward(mw, x[:1], cap, eps[:1], deterministic=False, r=0.8, noise_map=nm[:1]))
     import time
     dts = []
     for r_ in (0.6, 0.8):          # (the first call of a process can include the code object's load: the better of two counts)

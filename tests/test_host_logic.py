@@ -152,14 +152,35 @@ for step in range(3):
 # rewritten right after the call -- BEFORE the images of that step are consumed -- and two staging buffers / slabs alternate
 g2 = dp.OutputGather(even, 4, dst=0, overlap=True)
 slabs2 = []
+kept = []
 for step in range(5):
     even.fill_(100.0 * step + rank)
-    slab = g2()
+    assert g2() is None                       # overlap mode hands out no slab: it is rewritten two steps later (read through images())
     even.fill_(-1.0)                          # the next replay overwrites the static buffer: the staged copy must be what travels
     if rank == 0:
-        slabs2.append(slab.data_ptr())
+        slabs2.append(g2.slab.data_ptr())
         imgs = g2.images()
+        assert imgs.data_ptr() != g2.slab.data_ptr(), "images() of the double-buffered gather must be a copy"
+        kept.append(imgs)
         assert torch.all(imgs[:2] == 100.0 * step) and torch.all(imgs[2:] == 100.0 * step + 1), (step, imgs)
+if rank == 0:                                 # ... and the copies survive the reuse of both slabs
+    for step, imgs in enumerate(kept):
+        assert torch.all(imgs[:2] == 100.0 * step) and torch.all(imgs[2:] == 100.0 * step + 1), (step, imgs)
+# ragged shards (5 images over 2 ranks: 3 + 2) through the double-buffered gather over 5 steps: both staging buffers / slabs are
+# reused twice, the short shard's padding row never reaches images()
+lo, hi = dp.shard_bounds(total, rank, world)
+rag = torch.zeros(hi - lo, 3, 2, 2)
+g3 = dp.OutputGather(rag, total, dst=0, overlap=True)
+assert g3.sizes == [3, 2]
+for step in range(5):
+    rag.copy_(full[lo:hi] + 1000.0 * step)
+    g3()
+    rag.fill_(-7.0)
+    imgs = g3.images()
+    if rank == 0:
+        assert imgs.shape == (total, 3, 2, 2) and torch.equal(imgs, full + 1000.0 * step), (step, imgs)
+    else:
+        assert imgs is None
 dp.barrier()
 if rank == 0:
     assert torch.equal(out, full * 2.0), out

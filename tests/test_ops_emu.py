@@ -285,6 +285,20 @@ def test_gn_stats_large_offset_second_pass(emu_lib):
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, c=24, groups=3, h=10, w=12, mean=-40.0, std=0.05)   # odd group count, negative offset
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.float16, h=24, w=20, mean=100.0, std=0.2)          # 16-bit inputs (ulp 0.0625 at 100): single launch
     oc.check_gn_stats_offset(emu_lib, "cpu", torch.bfloat16, h=24, w=20, mean=30.0, std=0.3, finalize_only=True, nparts=7)   # bf16 (ulp 0.125 at 30)
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.bfloat16, c=64, groups=16, h=24, w=20, mean=100.0, std=0.3, finalize_only=True, nparts=7)   # bf16 above its flag ratio: 8-byte pieces (cpg 4)
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float16, c=40, groups=4, h=12, w=10, mean=200.0, std=0.2)                  # cpg 10 (UNet): 4-byte pieces
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float16, c=128, groups=8, h=12, w=10, mean=200.0, std=0.2)                 # cpg 16: 16-byte pieces
+
+
+def test_gn_stats_sliced_single_launch(emu_lib):
+    """Round 5: the single-launch statistics kernel with its pixels cut into slices (ticket counters, ABI v7): UNet shapes with
+    cpg 10 / 20 / 40 incl. a two-source concat whose seam lies inside a group set, the VAE's cpg 4, a ragged last slice, the
+    large-offset second pass from the last-arriving workgroup."""
+    oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, n=2, c0=320, groups=32, h=16, w=16, nparts=4, sliced=True)        # cpg 10, 4 slices of 64 px
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, n=1, c0=640, c1=320, groups=32, h=12, w=11, nparts=2, sliced=True)  # cpg 30, concat, ragged slice
+    oc.check_gn_stats(emu_lib, "cpu", torch.float16, n=2, c0=128, groups=32, h=16, w=24, nparts=6, sliced=True)         # cpg 4 (VAE), 6 slices
+    oc.check_gn_stats(emu_lib, "cpu", torch.float32, n=1, c0=64, groups=8, h=8, w=8, nparts=8, sliced=True)             # 64 px: one slice (falls back)
+    oc.check_gn_stats_offset(emu_lib, "cpu", torch.float32, c=64, groups=8, h=24, w=20, nparts=4, sliced=True)         # the flagged groups' second pass, from the last slice
 
 
 def test_gn_finalize_many_parts(emu_lib):

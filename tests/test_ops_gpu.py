@@ -45,6 +45,11 @@ def test_norms(gpu_lib, dtype):
     oc.check_gn_stats(gpu_lib, "cuda", dtype, n=2, c0=128, h=64, w=64, groups=32, nparts=16)
     oc.check_gn_stats(gpu_lib, "cuda", dtype, n=2, c0=1280, c1=640, h=8, w=8, groups=32, nparts=2)
     oc.check_gn_stats(gpu_lib, "cuda", dtype, n=1, c0=320, h=16, w=16, groups=32, nparts=4)
+    # sliced single launch (ticket counters, ABI v7): UNet planes at batch 1 and 8, concat input, VAE mid block
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=1, c0=320, h=64, w=64, groups=32, nparts=20, sliced=True)
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=8, c0=320, h=64, w=64, groups=32, nparts=20, sliced=True)
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=2, c0=640, c1=320, h=32, w=32, groups=32, nparts=15, sliced=True)
+    oc.check_gn_stats(gpu_lib, "cuda", dtype, n=1, c0=512, h=64, w=64, groups=32, nparts=32, sliced=True)
     oc.check_layernorm(gpu_lib, "cuda", dtype, rows=1000, c=1280)
     oc.check_layernorm(gpu_lib, "cuda", dtype, rows=77, c=320)
     oc.check_softmax(gpu_lib, "cuda", dtype, rows=500, cols=1024, ldp=1024)
@@ -303,8 +308,12 @@ def test_gn_stats_large_offset_second_pass(gpu_lib):
     """GroupNorm statistics with |mean| = 1000 sigma vs F.group_norm (two-pass): <= 1e-3 on the normalised output in fp32,
     through all three routes (single launch, partial + finalize, finalize over one-pass conv-epilogue partials)."""
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=64, w=64, groups=32)                      # single launch
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=64, w=64, groups=32, nparts=16, sliced=True)   # ... sliced (ABI v7 counters)
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=256, w=256, groups=32, nparts=64)         # partial + finalize
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=2, c=128, h=128, w=128, groups=32, nparts=512, finalize_only=True)
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float32, n=1, c=256, h=64, w=64, groups=32, mean=-30.0, std=0.02, nparts=16, finalize_only=True)
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=2, c=128, h=64, w=64, groups=32, mean=100.0, std=0.2)                            # 16-bit inputs
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.bfloat16, n=2, c=128, h=128, w=128, groups=32, mean=30.0, std=0.3, nparts=512, finalize_only=True)
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.bfloat16, n=2, c=128, h=128, w=128, groups=32, mean=100.0, std=0.3, nparts=512, finalize_only=True)   # above bf16's flag ratio
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=2, c=320, h=64, w=64, groups=32, mean=200.0, std=0.2)          # cpg 10 (UNet): 4-byte pieces
+    oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=1, c=512, h=64, w=64, groups=32, mean=200.0, std=0.2, nparts=16)   # cpg 16: 16-byte pieces
