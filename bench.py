@@ -166,6 +166,21 @@ def cpu_baseline(a, weights, x, cap, eps, noise):
                       "more threads are slower on these shapes)" % (a.size, a.size, CPU_BASELINE_TIMED, dt, os.cpu_count() or 0)}, out
 
 
+def add_activation_offset(weights, off):
+    """--activation-offset: every VAE resnet's conv2 bias += off (both VAEs of a CycleGAN model), in place, before packing."""
+    if not off:
+        return 0
+    n = 0
+    for sd in (weights.vae, getattr(weights, "vae_b2a", None)):
+        if sd is None:
+            continue
+        for k in list(sd):
+            if k.endswith(".conv2.bias") or k.endswith(".conv2.base_layer.bias"):
+                sd[k] = sd[k] + off
+                n += 1
+    return n
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -193,6 +208,13 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--serial-gather", action="store_true", help="N > 1: gather straight from the plan's output buffer on the launch stream (no overlap with the next replay)")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
+    ap.add_argument("--emulate", default=None, metavar="LIBI2I_TURBO_EMU_SO",
+                    help="TEST HOOK (tests/test_host_logic.py): run the whole bench flow -- rendezvous, shard, replay, double-buffered gather, "
+                         "max-over-ranks timing, the JSON line -- on the CPU wave emulator (tiny architecture, 64x64, gloo). Says nothing about speed.")
+    ap.add_argument("--activation-offset", type=float, default=0.0,
+                    help="add this constant to every VAE ResnetBlock2D conv2 bias: the residual streams then sit on DC offsets of tens to hundreds "
+                         "(what real SD-VAE activations do; the 1/sqrt(fan_in) synthetic weights keep everything zero-mean), GroupNorm groups trip the "
+                         "cancellation test and take the second, shifted pass (csrc/norm.hip gn_refine_group) -- prices that path in the step")
     a = ap.parse_args()
     global PER_OP_PATH
     PER_OP_PATH = a.per_op
@@ -212,13 +234,22 @@ def main():
     from img2img_turbo_amd.pix2pix_turbo import Pix2Pix_Turbo
     from img2img_turbo_amd.synth import make_cyclegan_weights, make_pix2pix_weights
 
-    rank, world, local = dp.init_from_env()
+    emu = a.emulate is not None
+    rank, world, local = dp.init_from_env("gloo" if emu else None)
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N`, which spawns the ranks, or "
                          "torch.distributed.run --nproc-per-node N)" % (a.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
+    lib_kw = {}
+    if emu:
+        from img2img_turbo_amd import _capi
+        dev, a.arch, a.size, a.dtype = "cpu", "tiny", 64, "f32"
+        a.no_cpu_baseline = a.no_latency = a.no_f32 = True
+        lib_kw = {"lib": _capi.Library(a.emulate)}
+        torch.cuda.synchronize = lambda *args, **kw: None       # (no streams on the CPU: every call below is synchronous)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        torch.cuda.set_device(local)
+        dev = "cuda:%d" % local
     dtype = DTYPES[a.dtype]
     ua, va = (SD_TURBO_UNET, SD_TURBO_VAE) if a.arch == "sd-turbo" else (TINY_UNET, TINY_VAE)
     B = a.batch
@@ -232,11 +263,13 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if a.model == "cyclegan":
         weights = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
-        model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype)
+        add_activation_offset(weights, a.activation_offset)
+        model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype, **lib_kw)
         kind, cfg = "photo", 3
     else:
         weights = make_pix2pix_weights(ua, va, seed=1234 + (4 if a.stochastic else 2), sketch=a.stochastic)
-        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype)
+        add_activation_offset(weights, a.activation_offset)
+        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype, **lib_kw)
         kind, cfg = ("sketch", 4) if a.stochastic else ("canny", 2)
     x, cap, eps, noise = synth_inputs(kind, B, a.size, ua.cross_attention_dim, va.latent_channels, 1234 + cfg + 1000 * rank)
     if a.model == "cyclegan":
@@ -292,6 +325,8 @@ def main():
                       "global_batch": total, "parallelism": "dp%d (batch shards, replicated weights, RCCL gather of outputs)" % world,
                       "arch": a.arch, "kernel_library": os.path.basename(model.lib.path)},
            "baseline_note": "vs_baseline = value / 9.09 img/s (0.11 s per 512x512 image on A100, reference README.md:17)"}
+    if a.activation_offset:
+        rec["config"]["activation_offset"] = a.activation_offset
     if world > 1:
         rec["ms_compute_per_rank"] = ms_compute                     # replay only (no gather), measured after the timed region
         rec["ms_gather"] = round(ms_per_step - max(ms_compute), 3)   # what the RCCL gather adds to the slowest rank's step
@@ -300,7 +335,9 @@ def main():
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":
         rec["e2e_mfma_frac"] = round(value / world * falg / 1e12 / PEAK_TF[a.dtype], 4)
-    if world == 1:
+    if emu:
+        rec["data"] = "EMULATED on the CPU (test hook): " + rec["data"]
+    if world == 1 and not emu:
         roof, breakdown, tot = kernel_roofline(plan, a.dtype)
         rec["roofline"] = roof
         rec["kernel_breakdown_ms"] = breakdown

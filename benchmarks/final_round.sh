@@ -6,7 +6,7 @@
 #   3. HBM traffic of the halo conv launches: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), corrected per
 #      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3.json keyed on the kernel-source hash
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
-TAG=${1:-r4}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
+TAG=${1:-r5}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
 CMD="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
 cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
@@ -17,6 +17,9 @@ python tools/pmc_traffic.py $F $W conv3x3_ --batch 8 --dtype bf16 --size 512 --s
     --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3.json
 cp $O/${TAG}_traffic_conv3x3.json profiles/traffic_conv3x3.json
 python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
+# the same step with every VAE resnet's conv2 bias + 30 (residual streams on DC offsets: GroupNorm groups take the second pass)
+python bench.py --activation-offset 30 --no-cpu-baseline --no-f32 --no-latency --steps 20 > $O/${TAG}_bench_bs8_offset30.json 2>> $O/${TAG}_bench_bs8.err
+python bench.py --activation-offset 30 --dtype f16 --steps 20 --no-f32 --no-latency > $O/${TAG}_bench_bs8_offset30_f16.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --batch 1 --no-cpu-baseline > $O/${TAG}_bench_bs1.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --batch 32 --no-cpu-baseline --steps 10 > $O/${TAG}_bench_bs32.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --model cyclegan --batch 4 --no-cpu-baseline > $O/${TAG}_bench_cfg3_cyclegan_bs4.json 2>> $O/${TAG}_bench_bs8.err
@@ -42,6 +45,12 @@ python tools/pmc_summary.py $(find $O/${TAG}_pmc/sq1 -name "*counter_collection.
 cat $O/${TAG}_pmc_conv3x3_summary.txt
 # 7. SQ + HBM counters of the wide GEMM (gemm_w32.hip) on its characteristic shapes: the GEGLU / ff.net.2 projections (tile 0 = auto) and the UNet's
 #    3x3 convolutions through its im2col gather (256 x 160 tiles)
-timeout 500 bash benchmarks/pmc_conv.sh $O/${TAG}_pmc_g32 "unet lin 1280->10240 T256,unet lin 1280->320 T4096,unet 960->320@64 gn,unet 320->320@64 gn" "--nogn --tiles 51" > /dev/null 2>&1
-python tools/pmc_summary.py $(find $O/${TAG}_pmc_g32 -name "*counter_collection.csv" | sort | tr '\n' ' ') gemm_w32_kernel > $O/${TAG}_pmc_gemm_w32_summary.txt 2>&1
+#    (one shape per pass set, so that the fetch of a projection and of a gathered 3x3 conv are attributable)
+: > $O/${TAG}_pmc_gemm_w32_summary.txt
+for shape in "unet lin 1280->320 T4096" "unet 960->320@64 gn"; do
+  d=$O/${TAG}_pmc_g32_$(echo "$shape" | tr -c 'a-zA-Z0-9' '_')
+  timeout 300 bash benchmarks/pmc_conv.sh $d "$shape" "--nogn --tiles 51" > /dev/null 2>&1
+  echo "== $shape" >> $O/${TAG}_pmc_gemm_w32_summary.txt
+  python tools/pmc_summary.py $(find $d -name "*counter_collection.csv" | sort | tr '\n' ' ') gemm_w32_kernel >> $O/${TAG}_pmc_gemm_w32_summary.txt 2>&1
+done
 cat $O/${TAG}_pmc_gemm_w32_summary.txt

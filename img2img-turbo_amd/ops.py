@@ -90,7 +90,7 @@ def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=
     p.ld1 = (ld1 if ld1 is not None else x1.shape[-1]) if x1 is not None else 0
     p.nimg, p.hw, p.groups, p.eps = nimg, hw, groups, eps
     p.gamma, p.beta, p.partial, p.nparts, p.ss = ptr(gamma), ptr(beta), ptr(partial), nparts, ptr(ss)
-    return K.OP_GN_STATS, p
+    return K.OP_GN_STATS, _keep(p, x0, x1, gamma, beta, partial, ss, counters)
 
 
 def gn_apply(x, y, ss, *, nimg, hw, c, act, ldx=0, ldy=0, ss_ld=0, ss_off=0, y_off=0):

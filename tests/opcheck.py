@@ -195,7 +195,8 @@ def check_gn_stats(lib, device, dtype, *, n=2, c0=32, c1=0, h=9, w=7, groups=8, 
     partial = torch.zeros(n * nparts * groups * 2, device=device)
     ss = torch.full((n, ct, 2), float("nan"), device=device)
     counters = torch.zeros(n * groups, dtype=torch.int32, device=device) if sliced else None
-    opcode, p = O.gn_stats(x0, gamma.to(device), beta.to(device), partial, ss, nimg=n, hw=h * w, groups=groups, eps=eps,
+    gd, bd = gamma.to(device), beta.to(device)          # (named: the descriptor holds raw pointers, and the op runs twice below)
+    opcode, p = O.gn_stats(x0, gd, bd, partial, ss, nimg=n, hw=h * w, groups=groups, eps=eps,
                            nparts=nparts, x1=x1, c0=c0, c1=c1, counters=counters)
     run_op(lib, opcode, p, dtype, device)
     err = rel_err(ss.cpu(), ref)
@@ -237,7 +238,8 @@ def check_gn_stats_offset(lib, device, dtype, *, n=2, c=32, h=48, w=40, groups=8
     else:
         partial = torch.zeros(n * nparts * groups * 2, device=device)
     counters = torch.zeros(n * groups, dtype=torch.int32, device=device) if sliced else None
-    opcode, p = O.gn_stats(x0, gamma.to(device), beta.to(device), partial, ss, nimg=n, hw=h * w, groups=groups, eps=1e-5,
+    gd, bd = gamma.to(device), beta.to(device)
+    opcode, p = O.gn_stats(x0, gd, bd, partial, ss, nimg=n, hw=h * w, groups=groups, eps=1e-5,
                            nparts=nparts, c0=c, finalize_only=1 if finalize_only else 0, counters=counters)
     run_op(lib, opcode, p, dtype, device)
     sc = ss.cpu()

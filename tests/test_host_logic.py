@@ -1,6 +1,7 @@
 """Host-side logic on the CPU: C-ABI surface, checkpoint readers (both reference layouts), packer folds,
 data-parallel sharding with a 2-process gloo group."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -410,6 +411,31 @@ def test_data_parallel_forward_two_ranks_gloo(tmp_path, emu_lib):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_E2E_OK" in outs[0]
+
+
+@pytest.mark.slow
+def test_bench_two_ranks_on_the_emulator(emu_lib, extra=()):
+    """`bench.py --gpus 2` end to end without a GPU: two gloo ranks on the CPU wave emulator (bench.py --emulate, a test hook) go
+    through the same rendezvous, batch sharding, replay + double-buffered / serial gather, barrier + max-over-ranks timing
+    and JSON line as the N > 1 runs the driver launches on RCCL.  Checked: ONE line, whole-job value, global batch, weak scaling,
+    per-rank compute times, ms_gather >= 0 up to timer noise."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29757", WORLD_SIZE="2")
+    env.pop("I2I_EMU_ASYNC", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--batch", "1", "--emulate", emu_lib.path] + list(extra)
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines()), "only rank 0 prints the JSON line"
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][0]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 0 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert rec["config"]["global_batch"] == 2 and "dp2" in rec["config"]["parallelism"]
+    assert abs(rec["value"] - 2 * 1e3 / rec["ms_per_step"]) < 1e-2 * rec["value"], "value is the whole-job rate (all ranks' images / max-over-ranks time)"
+    assert len(rec["ms_compute_per_rank"]) == 2 and all(t > 0 for t in rec["ms_compute_per_rank"])
+    assert rec["ms_gather"] > -0.25 * rec["ms_per_step"], rec            # step - compute: >= 0 up to run-to-run noise of two separate loops
+    assert ("serial" in rec["gather"]) == bool(extra)
+    assert "roofline" not in rec and rec["data"].startswith("EMULATED")
 
 
 def test_product_and_oracle_twins_of_arch_and_synth_agree():
