@@ -17,8 +17,18 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "gemm_w32.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip",
-           "attention.hip", "capi.hip", "runtime_hip.hip"]
+# "<file>" or "<file>#<n>": conv3x3_w32.hip is compiled as four translation units, one (dtype, tile) family of instantiations each
+# (-DW32_PART=n; the whole file in one unit is 4 minutes of hipcc), in parallel with everything else
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip",
+           "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "runtime_hip.hip"]
+
+
+def _split(src):
+    """'file.hip#n' -> (file.hip, ['-DW32_PART=n'], 'file_pn.o'); 'file.hip' -> (file.hip, [], 'file.o')."""
+    if "#" in src:
+        f, n = src.split("#")
+        return f, ["-DW32_PART=" + n], f.replace(".hip", "_p%s.o" % n)
+    return src, [], src.replace(".hip", ".o")
 HEADERS = ["i2i_dev.h", "launch.h", os.path.join("..", "..", "include", "i2i_turbo.h")]
 LIB = os.path.join(HERE, "libi2i_turbo.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -53,20 +63,23 @@ def _record(path, digest):
 
 def source_digest(src, defs=()):
     """What an object depends on: its source, the shared headers, the flags."""
-    return _digest([os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS], FLAGS + EXTRA_FLAGS.get(src, []) + list(defs))
+    f, part, _ = _split(src)
+    return _digest([os.path.join(HERE, f)] + [os.path.join(HERE, h) for h in HEADERS], FLAGS + EXTRA_FLAGS.get(f, []) + part + list(defs))
 
 
 def library_digest(defs=()):
-    return _digest([os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in HEADERS],
-                   FLAGS + [EXTRA_FLAGS.get(s, []) for s in SOURCES] + list(defs))
+    files = sorted({_split(s)[0] for s in SOURCES})
+    return _digest([os.path.join(HERE, f) for f in files] + [os.path.join(HERE, h) for h in HEADERS],
+                   FLAGS + [EXTRA_FLAGS.get(_split(s)[0], []) + _split(s)[1] for s in SOURCES] + list(defs))
 
 
 def _compile(src, force, bdir="build", defs=()):
-    obj = os.path.join(HERE, bdir, src.replace(".hip", ".o"))
+    f, part, oname = _split(src)
+    obj = os.path.join(HERE, bdir, oname)
     want = source_digest(src, defs)
     if not force and os.path.exists(obj) and _recorded(obj) == want:
         return obj, "reused"
-    cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defs) + ["-c", os.path.join(HERE, src), "-o", obj]
+    cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(f, []) + part + list(defs) + ["-c", os.path.join(HERE, f), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -837,17 +837,31 @@ void w32_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
     else { *th = 16; *bn = 128; *wtn = 128; }
 }
 
-template <typename T>
-int launch_w32_t(const i2i_igemm_params& p, hipStream_t s) {
-    switch (w32_cfg(p)) {
-        case 41: return launch_w32<T, 8, 256, 2, 2>(p, s);
-        case 42: return launch_w32<T, 16, 128, 4, 1>(p, s);
-    }
-    return i2i::fail(I2I_ERR_BAD_ARG, "conv3x3_w32: unknown tile config %d", p.tile);
-}
-
 }  // namespace
 
+// ---- The four (dtype, tile) families of instantiations.  W32_PART (0 .. 3, csrc/build.py and tests/emu/build_emu.py) compiles ONE
+// family per translation unit -- the whole file is 32 kernels of 35 - 65 KB of code each, 4 minutes of hipcc and 20 of host clang
+// for the emulator in one unit; part 0 also holds the dispatcher and the eligibility rules.  Without W32_PART: everything.
+namespace i2i {
+int w32_launch_bf16_41(const i2i_igemm_params& p, hipStream_t s);
+int w32_launch_bf16_42(const i2i_igemm_params& p, hipStream_t s);
+int w32_launch_f16_41(const i2i_igemm_params& p, hipStream_t s);
+int w32_launch_f16_42(const i2i_igemm_params& p, hipStream_t s);
+#if !defined(W32_PART) || W32_PART == 0
+int w32_launch_bf16_41(const i2i_igemm_params& p, hipStream_t s) { return launch_w32<__bf16, 8, 256, 2, 2>(p, s); }
+#endif
+#if !defined(W32_PART) || W32_PART == 1
+int w32_launch_bf16_42(const i2i_igemm_params& p, hipStream_t s) { return launch_w32<__bf16, 16, 128, 4, 1>(p, s); }
+#endif
+#if !defined(W32_PART) || W32_PART == 2
+int w32_launch_f16_41(const i2i_igemm_params& p, hipStream_t s) { return launch_w32<_Float16, 8, 256, 2, 2>(p, s); }
+#endif
+#if !defined(W32_PART) || W32_PART == 3
+int w32_launch_f16_42(const i2i_igemm_params& p, hipStream_t s) { return launch_w32<_Float16, 16, 128, 4, 1>(p, s); }
+#endif
+}  // namespace i2i
+
+#if !defined(W32_PART) || W32_PART == 0
 namespace i2i {
 // Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
 // counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
@@ -891,10 +905,13 @@ int conv3x3_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     return ((pl_w + W32_TW - 1) / W32_TW) * ((pl_h + th - 1) / th) * (p.subpix ? 4 : 1);      // one slot per tile (and parity)
 }
 int conv3x3_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
+    const int cfg = w32_cfg(p);
+    if (cfg != 41 && cfg != 42) return fail(I2I_ERR_BAD_ARG, "conv3x3_w32: unknown tile config %d", p.tile);
     switch (dtype) {
-        case I2I_BF16: return launch_w32_t<__bf16>(p, s);
-        case I2I_F16: return launch_w32_t<_Float16>(p, s);
+        case I2I_BF16: return cfg == 41 ? w32_launch_bf16_41(p, s) : w32_launch_bf16_42(p, s);
+        case I2I_F16: return cfg == 41 ? w32_launch_f16_41(p, s) : w32_launch_f16_42(p, s);
     }
     return fail(I2I_ERR_BAD_ARG, "conv3x3_w32: bad dtype");
 }
 }  // namespace i2i
+#endif  // W32_PART == 0

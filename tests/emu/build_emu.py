@@ -14,7 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip", "gemm_dma.hip", "gemm_w32.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip"]
+# "<file>#<n>": conv3x3_w32.hip as four translation units (-DW32_PART=n, one family of instantiations each: csrc/build.py) -- the
+# whole file in one unit is 20 minutes of host clang
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip",
+           "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip"]
 OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
          "-Wno-unused-function", "-Wno-unknown-attributes"]
@@ -43,7 +46,11 @@ def build(tag=None, extra=()):
     bdir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
     out = OUT if not tag else os.path.join(bdir, "libi2i_turbo_emu_%s.so" % tag)
     os.makedirs(bdir, exist_ok=True)
-    jobs = [(os.path.join(CSRC, s), os.path.join(bdir, s.replace(".hip", ".emu.o")), True, extra) for s in SOURCES]
+    jobs = []
+    for s in SOURCES:
+        f, _, n = s.partition("#")
+        part = ("-DW32_PART=" + n,) if n else ()
+        jobs.append((os.path.join(CSRC, f), os.path.join(bdir, f.replace(".hip", (".p%s" % n if n else "") + ".emu.o")), True, tuple(extra) + part))
     jobs += [(os.path.join(HERE, "hip_emu.cpp"), os.path.join(bdir, "hip_emu.o"), False, extra),
              (os.path.join(HERE, "runtime_emu.cpp"), os.path.join(bdir, "runtime_emu.o"), False, extra)]
     with cf.ThreadPoolExecutor(max_workers=8) as ex:
