@@ -226,27 +226,45 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
     const char* vp = (const char*)((const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)h * D * p.ldvt);
-    const char* zero = (const char*)g_att_zero16;
     const int ntile = (p.tk + BKV - 1) / BKV;
 
-    // this wave's DMA pieces: pc = wave*4 + q; pc < 8: K rows pc*8.. (row = key), else V^T rows (pc-8)*8.. (row = d)
+    // this wave's DMA pieces: pc = wave*4 + q; pc < 8 (waves 0, 1): K rows pc*8.. (row = key), else V^T rows (pc-8)*8.. (row = d).
+    // The lane offsets of tile 0 are computed ONCE; a tile adds a wave-uniform stride to the scalar base (64 keys: 64 rows of K,
+    // 128 bytes of every V^T row).  (Round 5: the per-tile form -- key / chunk validity tests and 64-bit address arithmetic per
+    // piece, compiled to exec-mask branches -- was ~190 of the ~800 instructions a wave issued per tile in a VALU-bound loop.)
+    // Keys past tk exist only in the LAST tile: there K rows past the end re-read the last key (masked in the softmax) and V^T
+    // chunks past the end come from a zero block (the partially valid chunk is cleaned in LDS below).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool k_wave = wave_u < 2;
+    unsigned d_off[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pc = wave_u * PPW + q;
+        const int row = (pc & 7) * 8 + (lane >> 3);
+        const int sc = (lane & 7) ^ ((row >> 1) & 7);                     // source chunk of physical chunk lane&7 (att_off<8>)
+        d_off[q] = k_wave ? (unsigned)(row * p.ldk + sc * 8) * (unsigned)sizeof(T) : (unsigned)(row * p.ldvt + sc * 8) * (unsigned)sizeof(T);
+    }
     auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
         const int kv0 = t * BKV;
         char* dst = i2i_smem + stage * STAGE;
+        if (kv0 + BKV <= p.tk) {                                          // (wave-uniform)
+            const char* base = k_wave ? kp + (size_t)kv0 * p.ldk * sizeof(T) : vp + (size_t)kv0 * sizeof(T);
 #pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const int pc = wave * PPW + q;
-            const int row = (pc & 7) * 8 + (lane >> 3);
-            const int sc = (lane & 7) ^ ((row >> 1) & 7);                 // source chunk of physical chunk lane&7 (att_off<8>)
-            const char* src;
-            if (pc < 8) {
-                const int key = kv0 + row;
-                src = key < p.tk ? kp + ((size_t)key * p.ldk + sc * 8) * sizeof(T) : zero;
-            } else {
-                const int key0 = kv0 + sc * 8;
-                src = key0 < p.tk ? vp + ((size_t)row * p.ldvt + key0) * sizeof(T) : zero;
+            for (int q = 0; q < PPW; ++q) glds16_sv(base, d_off[q], dst + (wave_u * PPW + q) * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                const int pc = wave_u * PPW + q;
+                const int row = (pc & 7) * 8 + (lane >> 3);
+                const int sc = (lane & 7) ^ ((row >> 1) & 7);
+                if (k_wave) {                                             // rows past tk: the last key again (masked below)
+                    const int key = kv0 + row < p.tk ? kv0 + row : p.tk - 1;
+                    glds16_sv(kp, (unsigned)(key * p.ldk + sc * 8) * (unsigned)sizeof(T), dst + pc * 1024);
+                } else {                                                  // chunks past tk: zeros (the pad columns of V^T may hold anything)
+                    const int key0 = kv0 + sc * 8;
+                    glds16(key0 < p.tk ? vp + (size_t)(row * p.ldvt + key0) * sizeof(T) : (const char*)g_att_zero16, dst + pc * 1024);
+                }
             }
-            glds16(src, dst + pc * 1024);
         }
     };
 

@@ -169,13 +169,20 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     char* w_dst = i2i_smem;
     // GATHER: (tap, channel offset) of the NEXT window to open -- windows open in stage order, so the decode is a running
     // counter in scalar registers -- and of the open one: tap index (bit of a_ok) and byte offset of (tap pixel, channels)
+    // Stage order of the gather (round 5): the NINE TAPS of a 64-channel slab run back to back (stage s = tap s % 9 of slab s / 9;
+    // the contraction index of stage s is tap * cin + slab * 64 in the [tap][cin] weight layout).  With the taps outermost -- all
+    // cin / 64 slabs of tap 0, then tap 1, ... -- a tile came back to the same pixels only after cin / 64 stages: 15 MB of A
+    // operand per XCD between two visits at 960 channels, against 4 MiB of L2, so every tap re-fetched its pixels through the
+    // fabric (PMC: 599 MB fetched per launch for 63 MB of input at 960 -> 320 @ 64 x 64, 3.8 TB/s: the launch was fabric-bound).
     int g_tap = 0, g_ky = 0, g_kx = 0, g_ci = 0;
     if constexpr (GATHER && SPLITK) {                     // the slice's first stage
-        g_tap = (s0 * BK) / p.c0;
-        g_ci = s0 * BK - g_tap * p.c0;
+        const int slab0 = s0 / 9;
+        g_tap = s0 - slab0 * 9;
+        g_ci = slab0 * BK;
         g_ky = g_tap / 3;
         g_kx = g_tap - g_ky * 3;
     }
+    unsigned w_koff = 0u;                                 // GATHER: byte offset of the open window's stage in a weight row
     unsigned w_tap = 0u, w_aoff = 0u;
     auto open_window = [&](int s, int slot) __attribute__((always_inline)) {      // s < 0: dummy window
         const bool on = s >= 0;
@@ -186,15 +193,18 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
         } else {
             w_tap = (unsigned)g_tap;
             w_aoff = (unsigned)((g_ky * p.win + g_kx) * p.lda0 + g_ci) * 2u;
-            g_ci += BK;                                    // (selects, not branches: the K loop stays one basic block per half)
-            const int wrap = g_ci == p.c0 ? 1 : 0;
-            g_ci = wrap ? 0 : g_ci;
-            g_tap += wrap; g_kx += wrap;
+            w_koff = (unsigned)(g_tap * p.c0 + g_ci) * 2u;
+            g_tap += 1; g_kx += 1;                         // (selects, not branches: the K loop stays one basic block per half)
             const int wrap3 = g_kx == 3 ? 1 : 0;
             g_kx = wrap3 ? 0 : g_kx;
             g_ky += wrap3;
+            const int wrap9 = g_tap == 9 ? 1 : 0;
+            g_tap = wrap9 ? 0 : g_tap;
+            g_ky = wrap9 ? 0 : g_ky;
+            g_ci += wrap9 ? BK : 0;
         }
-        w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s + s0) * (BK * 2) : zero;
+        if constexpr (GATHER) w_bbase = on ? bw + w_koff : zero;
+        else w_bbase = on ? bw + (size_t)(s < 0 ? 0 : s + s0) * (BK * 2) : zero;
         w_msk = on ? 0xffffffffu : 0u;
         w_dst = i2i_smem + slot * STAGE;
         sopaque(w_msk);                                    // (the ksteps must not be specialised on the window kind)
