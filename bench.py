@@ -181,6 +181,53 @@ def add_activation_offset(weights, off):
     return n
 
 
+def _smi_sample():
+    """One `amd-smi metric` reading of GPU 0: (socket power W, mean gfx clock MHz over the XCDs, max gfx clock MHz) or None."""
+    import subprocess
+    try:
+        r = subprocess.run(["amd-smi", "metric", "-g", "0", "--power", "--clock", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        d = (d.get("gpu_data") if isinstance(d, dict) else d)[0]
+        pw = d["power"]["socket_power"]["value"]
+        ck = [v["clk"]["value"] for k, v in d["clock"].items() if k.startswith("gfx_") and isinstance(v.get("clk", {}).get("value"), (int, float))]
+        mx = [v["max_clk"]["value"] for k, v in d["clock"].items() if k.startswith("gfx_") and isinstance(v.get("max_clk", {}).get("value"), (int, float))]
+        return float(pw), sum(ck) / len(ck), float(max(mx))
+    except Exception:        # tool missing / different schema: the field is simply absent from the line
+        return None
+
+
+def power_and_clock(plan, seconds=3.0):
+    """Socket power and shader clock while the benchmarked graph replays back to back (outside the timed region).
+
+    The big MFMA kernels of this path run at the chip's power budget on random data (profiles/r5h_power_probe_*.log: 1.29-1.38 kW
+    of the 1.4 kW cap, shader clock 1.8-2.0 GHz of 2.4): the roofline's `peak` is the guide's 2.4 GHz figure, this says what clock
+    the measured step actually had.
+    """
+    import threading
+    rows, stop = [], []
+
+    def loop():
+        while not stop:
+            s = _smi_sample()
+            if s:
+                rows.append(s)
+
+    th = threading.Thread(target=loop, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        plan.replay()
+        torch.cuda.synchronize()
+    stop.append(1)
+    th.join(timeout=30)
+    rows = rows[1:] if len(rows) > 2 else rows          # the first reading may predate the ramp
+    if not rows:
+        return None
+    n = len(rows)
+    return {"socket_w": round(sum(r[0] for r in rows) / n, 1), "gfx_mhz": round(sum(r[1] for r in rows) / n, 1), "gfx_max_mhz": rows[0][2], "samples": n,
+            "how": "amd-smi metric --power --clock polled while the same graph replays for %.0f s after the timed region" % seconds}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -205,6 +252,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32-mode replays (images_per_s_f32 / parity_max_abs_f32) of the N = 1 line")
+    ap.add_argument("--no-power", action="store_true", help="skip the amd-smi socket-power / shader-clock reading of the N = 1 line")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--serial-gather", action="store_true", help="N > 1: gather straight from the plan's output buffer on the launch stream (no overlap with the next replay)")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
@@ -342,6 +390,11 @@ def main():
         rec["roofline"] = roof
         rec["kernel_breakdown_ms"] = breakdown
         rec["sum_kernel_ms"] = round(tot, 3)
+        pc = None if a.no_power else power_and_clock(plan)
+        if pc:
+            rec["power"] = pc
+            if roof and roof.get("frac") and pc["gfx_mhz"] > 0:
+                roof["frac_at_measured_clock"] = round(roof["frac"] * pc["gfx_max_mhz"] / pc["gfx_mhz"], 4)
         # throughput through the public forward() (boundary copies + output clone included), same batch
         fw = {"caption_enc" if a.model == "pix2pix" else "caption_emb": cap.to(dev), "eps": eps.to(dev)}
         if a.model == "cyclegan":

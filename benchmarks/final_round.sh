@@ -7,7 +7,7 @@
 #      MI355X_MICROARCH.md, written to profiles/traffic_conv3x3.json keyed on the kernel-source hash
 #   4. one line each for the other BASELINE configurations at N = 1 (bs=1, bs=32, cfg 3, cfg 4, cfg 5)
 TAG=${1:-r5}; O=gpurun_out; export TMPDIR=/tmp; mkdir -p $O
-CMD="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency --no-f32"
+CMD="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency --no-f32 --no-power"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o trace -- $CMD > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err
 cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_bs8_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o fetch -- $CMD > /dev/null 2> $O/${TAG}_fetch.err

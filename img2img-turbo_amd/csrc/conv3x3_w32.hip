@@ -68,6 +68,21 @@ template <typename V> __device__ __forceinline__ void opaque(V&) {}
 template <typename V> __device__ __forceinline__ void opaque(V& x) { asm volatile("" : "+v"(x)); }
 #endif
 
+// One accumulator value, read out of its AGPR where the epilogue uses it.  With plain uses hipcc gives the accumulators' loop-exit values
+// the VGPR class (every use is a VALU instruction) and copies ALL 256 of them out of the AGPRs at the top of the epilogue: three quarters
+// fit, the rest are shuffled between AGPRs (75 v_accvgpr_mov) and spilled, and the spill reloads' vmcnt(0) then wait for the tile's own
+// global stores.  An "a"-constraint operand keeps the value where the MFMA left it until this instruction.  (The last MFMA and the first
+// read are a workgroup barrier and dozens of instructions apart: no hand-placed wait states needed.)
+#ifdef I2I_EMU
+__device__ __forceinline__ float acc_rd(float a) { return a; }
+#else
+__device__ __forceinline__ float acc_rd(float a) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+#endif
+
 // c + a.x*b.x + a.y*b.y in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -627,8 +642,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     typedef T tx2 __attribute__((ext_vector_type(2)));
     const T* __restrict__ res = (const T*)p.res;
     const bool do_stats = p.gn_part != nullptr;
-    auto epilogue = [&](int img, int ty0, int tx0) __attribute__((always_inline)) {
-        constexpr bool FULL = false;
+    auto epilogue = [&](auto fullc, int img, int ty0, int tx0) __attribute__((always_inline)) {
+        // FULL: the tile lies inside the plane and the channel range (every tile of the model's shapes at 512 x 512): no store predicates
+        // -- hipcc turns each into an exec-mask branch around its store, which also makes its vmcnt bookkeeping pessimistic (a residual
+        // row's wait became vmcnt(0): the previous rows' STORES had to complete first) -- and no zeroing of masked chunks
+        constexpr bool FULL = decltype(fullc)::value != 0;
         // every lane constant of the epilogue is re-derived from an opaque copy of the lane id: otherwise LICM computes
         // the staging / store addresses once per kernel and they sit in (spilled) registers across the whole tile stream
         int elane = lane;
@@ -673,7 +691,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
 #pragma unroll
                 for (int k = 0; k < SPX / 4; ++k) {
                     const bool ok = FULL || (rowok && nok && tx0 + k * 4 + p4 < p.wo);
-                    rr[(i - NPRE) % RDEPTH][k] = *(const chunk_t*)(rbase + (ok ? (unsigned)(k * 4 * p.ldr) + r_lane : 0u));
+                    // (uniform 64-bit base + 32-bit BYTE offset per lane: the scalar-base form of the load, no 64-bit VALU address per chunk)
+                    rr[(i - NPRE) % RDEPTH][k] = *(const chunk_t*)((const char*)rbase + (ok ? ((unsigned)(k * 4 * p.ldr) + r_lane) * (unsigned)sizeof(T) : 0u));
                 }
             }
         };
@@ -707,18 +726,45 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                     const int px = l31 % SPX;
                     char* const prow = stg + px * 256 + 8 * lh;
                     const int pswz = (px & 15) << 4;
+                    // The bias quads (and the staged residual quads) of channel fragment j + 1 are read BEFORE fragment j's pieces are
+                    // written: hipcc cannot tell the staging image from the bias block (both LDS, dynamic offsets), so a read placed after
+                    // a piece's store waits for it -- the first form (read, wait, 4 FMAs, store, per piece) exposed one LDS round trip per
+                    // piece, 64-128 per tile (W32_EPI_BATCH=0: that form, the A/B baseline).
+#ifndef W32_EPI_BATCH
+#define W32_EPI_BATCH 1
+#endif
+                    // (with a residual the next row's chunks are in flight in rr[] as well: the quads of fragment j are then read at the top of
+                    // ITS region -- one round trip per fragment, half the registers -- instead of one fragment ahead)
+                    constexpr int PF = RES ? 0 : 1, NB = PF + 1;
+                    f32x4 bqv[NB][4];
+                    tx4 rqv[NB][4];
+                    auto quads = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        __builtin_amdgcn_sched_barrier(0);    // four pieces at a time: 16 accumulators + 16 bias values live
+                        for (int q = 0; q < 4; ++q) bqv[j % NB][q] = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + blane);
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rqv[j % NB][q] = *(const tx4*)(prow + (((j * 4 + q) << 4) ^ pswz));
+                        }
+                    };
+                    if constexpr (W32_EPI_BATCH && PF) quads(icw<0>{});
+                    static_for_w<FN>([&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        __builtin_amdgcn_sched_barrier(0);    // four pieces at a time: 16 accumulators + 2 x 16 bias values live
+                        if constexpr (W32_EPI_BATCH && j + PF < FN) quads(icw<j + PF>{});
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             char* const a = prow + (((j * 4 + q) << 4) ^ pswz);
-                            const f32x4 bq = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + blane);
+                            f32x4 bq;
+                            if constexpr (W32_EPI_BATCH) bq = bqv[j % NB][q];
+                            else bq = *(const f32x4*)(i2i_smem + BI0 + (wn * WTN + j * 32 + 8 * q) * 4 + blane);
                             float v[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(p.alpha, acc[i][j][4 * q + r], bq[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(p.alpha, W32_EPI_BATCH ? acc_rd(acc[i][j][4 * q + r]) : acc[i][j][4 * q + r], bq[r]);
                             if constexpr (RES) {
-                                const tx4 r4 = *(const tx4*)a;
+                                tx4 r4;
+                                if constexpr (W32_EPI_BATCH) r4 = rqv[j % NB][q];
+                                else r4 = *(const tx4*)a;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(r4[r]);
                             }
@@ -727,19 +773,31 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
                             for (int r = 0; r < 4; ++r) o4[r] = from_f32<T>(v[r]);
                             *(tx4*)a = o4;
                         }
-                    }
+                    });
                 }
                 wave_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (RES && RAHEAD && i < NPRE && i + RDEPTH >= NPRE && BN != 128) res_load(icw<i + RDEPTH>{});
                 // (c) whole rows back: full-line stores + statistics of what is stored
-                T* const orow = obase + o_lane;
+                const unsigned o_lane_b = o_lane * (unsigned)sizeof(T);      // (byte offset: scalar row base + 32-bit lane offset in the store)
+                // (the row chunks are read CB at a time and pinned: hipcc otherwise sinks each read into its store's predicate branch --
+                // read, lgkmcnt(0), store, eight LDS round trips per tile row; four at a time beside a residual row in flight)
+                constexpr int CB = !W32_EPI_BATCH ? 1 : (RES ? 4 : SPX / 4);
+                chunk_t cq[CB];
 #pragma unroll
                 for (int k = 0; k < SPX / 4; ++k) {
+                    if (k % CB == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < CB; ++kk) cq[kk] = *(const chunk_t*)(stg + ((rl_off + (k + kk) * 1024) ^ ((((k + kk) * 4) & 12) << 4)));
+                        if constexpr (W32_EPI_BATCH) {
+#pragma unroll
+                            for (int kk = 0; kk < CB; ++kk) opaque(cq[kk]);
+                        }
+                    }
                     const int pxr = rd * SPX + k * 4;
-                    chunk_t c = *(const chunk_t*)(stg + ((rl_off + k * 1024) ^ (((k * 4) & 12) << 4)));
+                    chunk_t c = cq[k % CB];
                     const bool ok = FULL || (rowok && nok && tx0 + pxr + p4 < pl_w);
-                    if (ok && !W32_ABL(1)) *(chunk_t*)(orow + (unsigned)(PXS * pxr * p.ldc)) = c;
+                    if (ok && !W32_ABL(1)) *(chunk_t*)((char*)(obase + (unsigned)(PXS * pxr * p.ldc)) + o_lane_b) = c;
                     if (!FULL && !ok) c = zero_chunk<T>();
                     tx2 d0, d1, d2, d3;
                     d0[0] = c[0]; d0[1] = c[1]; d1[0] = c[2]; d1[1] = c[3]; d2[0] = c[4]; d2[1] = c[5]; d3[0] = c[6]; d3[1] = c[7];
@@ -783,7 +841,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             lds_barrier();                                   // the staging blocks are free again
         }
     };
-    epilogue(img, ty0, tx0);
+#ifndef W32_EPI_FULL
+#define W32_EPI_FULL 1
+#endif
+    if (W32_EPI_FULL && ty0 + TH <= pl_h && tx0 + TW <= pl_w && n0 + BN <= p.N) epilogue(icw<1>{}, img, ty0, tx0);      // (uniform)
+    else epilogue(icw<0>{}, img, ty0, tx0);
 #ifdef I2I_TRACE
     W32_TR(6);
     if (p.ws && lane == 0) {

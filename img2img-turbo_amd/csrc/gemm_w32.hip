@@ -342,9 +342,177 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     typedef T tx8 __attribute__((ext_vector_type(8)));
     const T* __restrict__ res = (const T*)p.res;
     T* __restrict__ out = (T*)p.c;
+    constexpr int NV = STATS ? FNW * 8 : 1;              // STATS: (sum, sum of squares) of the lane's stored values per 4-channel quad
+    auto stats_out = [&](float (&gacc)[NV]) __attribute__((always_inline)) {
+        // ---- GroupNorm partial sums of the stored tile (the next layer's norm): lane (l31, lh) holds NV sums over ITS row(s);
+        // rows -> wave through an LDS transpose (lane t adds value t % 32 of the 32 lanes of half t / 32: fixed order), waves ->
+        // workgroup -> one slot per (image, row tile, group).  The operand ring is dead: every wave's DMA has landed (the
+        // wait above) and the barrier below says every wave is done reading it.
+        if constexpr (STATS) {
+            static_assert(!STATS || NV == 32, "one value per lane and half: FNW == 4");
+            if (p.gn_part) {
+                constexpr int LST = NV + 4;                   // lane stride in floats: 16-byte writes of 16 lanes hit 16 distinct bank quads
+                float* st = (float*)i2i_smem;                 // [NW][64][LST]
+                float* st2 = st + NW * 64 * LST;              // [NW][32 quads][2]
+                lds_barrier();
+#pragma unroll
+                for (int v = 0; v < NV; v += 4)
+                    *(f32x4*)(st + (wave * 64 + lane) * LST + v) = f32x4{gacc[v], gacc[v + 1], gacc[v + 2], gacc[v + 3]};
+                lds_barrier();
+                {
+                    const int half = lane >> 5, v = lane & 31;
+                    float tot = 0.f;
+                    for (int l = 0; l < 32; ++l) tot += st[(wave * 64 + half * 32 + l) * LST + v];
+                    const int jpr = v >> 2, h = (v >> 1) & 1, sq = v & 1;        // v = ((j*2 + pr)*2 + h)*2 + sq
+                    const int quad = jpr * 4 + half * 2 + h;                      // column quad of the tile: j*8 + pr*4 + lh*2 + h
+                    st2[(wave * 32 + quad) * 2 + sq] = tot;
+                }
+                lds_barrier();
+                const int groups = p.gn_part_groups, cpg = p.N / groups, ng_tile = BN / cpg;
+                const int g = n0 / cpg + tid;
+                if (tid < ng_tile && g < groups) {
+                    const int q0 = (tid * cpg) >> 2, nq = cpg >> 2;
+                    float S = 0.f, Q = 0.f;
+                    for (int w = 0; w < NW; ++w)
+                        for (int q = q0; q < q0 + nq; ++q) { S += st2[(w * 32 + q) * 2]; Q += st2[(w * 32 + q) * 2 + 1]; }
+                    const int hw = p.ho * p.wo, parts = hw / BM;
+                    const int img = m0 / hw, part = (m0 - img * hw) / BM;
+                    float* o2 = p.gn_part + (((int64_t)img * parts + part) * groups + g) * 2;
+                    o2[0] = S;
+                    o2[1] = Q;
+                }
+            }
+        }
+    };
+#ifndef G32_EPI_PIPE
+#define G32_EPI_PIPE 1
+#endif
+    // ---- The pipelined epilogue (G32_EPI_PIPE=0: the first form below, the A/B baseline).  The first form fetched each column block's
+    // bias and residual at its use, behind runtime branches: load, vmcnt(0) -- which also waits for the previous block's STORES --, FMAs,
+    // store, 2 x FNW times per tile: ten serial HBM round trips on a 256 x 160 tile whose K loop (K = 320) is 200 MFMAs.  Here the bias
+    // and the residual of block t + 1 are requested before block t's stores (branch-free: hipcc's own vmcnt counts are then exact and do not
+    // wait for a store), and tiles inside M x N (all of them on this model's shapes) take an instantiation without predicates.
+    constexpr int NBLK = GEGLU ? FNW : 2 * FNW;          // column blocks of 8 OUTPUT columns per lane: (j, pr), or j for GEGLU
+    auto pipe = [&](auto fullc, auto resc) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(fullc)::value != 0, RES = decltype(resc)::value != 0;
+        const int mrow = m0 + wave * WTM + l31;           // + i*32
+        auto col_in = [&](auto tc) __attribute__((always_inline)) {      // first packed (input) column of block t's bias
+            constexpr int t = decltype(tc)::value;
+            if constexpr (GEGLU) return n0 + t * 32; else return n0 + (t >> 1) * 32 + 16 * (t & 1) + 8 * lh;
+        };
+        auto col_out = [&](auto tc) __attribute__((always_inline)) {     // first output column of the lane's 8 results of block t
+            constexpr int t = decltype(tc)::value;
+            if constexpr (GEGLU) return (n0 + t * 32) / 2 + 8 * lh; else return n0 + (t >> 1) * 32 + 16 * (t & 1) + 8 * lh;
+        };
+        auto col_ok = [&](auto tc) __attribute__((always_inline)) {
+            if constexpr (FULL) return true;
+            else if constexpr (GEGLU) return col_in(tc) + 32 <= p.N;      // N % 32 == 0 (host check)
+            else return col_in(tc) < p.N;                                  // N % 8 == 0: a chunk is inside or outside as a whole
+        };
+        // bias of block t (4 x 16 bytes for GEGLU: value and gate quads; 2 x 16 bytes otherwise), double-buffered like the residual and
+        // branch-free: without a bias the loads read the first bytes of the weights and the values are selected away
+        constexpr int NBQ = GEGLU ? 4 : 2;
+        f32x4 bb[2][NBQ];
+        const bool has_bias = GEGLU ? p.bias != nullptr : p.bias_mode == 1;
+        const float* const bsrc = has_bias ? p.bias : (const float*)p.b;
+        auto bload = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < NBLK) {
+                const int nb = (has_bias && col_ok(tc)) ? col_in(tc) : 0;      // (clamped: lanes outside N never store)
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) {
+                    const f32x4 b = *(const f32x4*)(bsrc + nb + (GEGLU ? 8 * q + 4 * lh : 4 * q));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bb[t & 1][q][r] = has_bias ? b[r] : 0.f;
+                }
+            }
+        };
+        chunk_t rr[2][FMW];
+        auto rload = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (RES && t < NBLK) {
+                const bool nok = col_ok(tc);
+                const int no = col_out(tc);
+#pragma unroll
+                for (int i = 0; i < FMW; ++i) {
+                    const int m = mrow + i * 32;
+                    const bool ok = FULL || (nok && m < p.M);
+                    rr[t & 1][i] = *(const chunk_t*)(res + (ok ? (int64_t)m * p.ldr + no : 0));
+                }
+            }
+        };
+        typedef T tx2 __attribute__((ext_vector_type(2)));
+        float gacc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) gacc[v] = 0.f;
+        tx2 ones;
+        ones[0] = (T)1.0f; ones[1] = (T)1.0f;
+        bload(icg<0>{});
+        rload(icg<0>{});
+        static_for_g<NBLK>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            bload(icg<t + 1>{});                              // the next block's bias and residual: issued before this block's stores
+            rload(icg<t + 1>{});
+            const bool nok = col_ok(tc);
+            const int no = col_out(tc);
+#pragma unroll
+            for (int i = 0; i < FMW; ++i) {
+                f32x4 qa, qb;
+                if constexpr (GEGLU) {
+                    // weight rows (and bias) are interleaved per 32 as [16 value rows | 16 gate rows] (packer.geglu_linear): a fragment's
+                    // registers 0..7 are values and 8..15 the gates of the SAME 16 output columns: out = value * gelu(gate), lane-local
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = __builtin_fmaf(p.alpha, acc[i][t][4 * q + r], bb[t & 1][q][r]);
+                            const float g = __builtin_fmaf(p.alpha, acc[i][t][8 + 4 * q + r], bb[t & 1][2 + q][r]);
+                            const float o = a * gelu_erf_f(g);
+                            if (q == 0) qa[r] = o; else qb[r] = o;
+                        }
+                } else {
+                    constexpr int j = t >> 1, pr = t & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qa[r] = acc[i][j][8 * pr + r]; qb[r] = acc[i][j][8 * pr + 4 + r]; }
+                }
+                float v[8];
+                widen_pair(qa, qb, v);                     // wave-wide: before any lane drops out
+                const int m = mrow + i * 32;
+                if (!FULL && (!nok || m >= p.M)) continue;
+                if constexpr (!GEGLU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = __builtin_fmaf(p.alpha, v[r], bb[t & 1][0][r]); v[4 + r] = __builtin_fmaf(p.alpha, v[4 + r], bb[t & 1][1][r]); }
+                }
+                if constexpr (RES) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += to_f32<T>(rr[t & 1][i][r]);
+                }
+                tx8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(v[r]);
+                *(tx8*)(out + (int64_t)m * p.ldc + no) = o;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        tx2 d0, d1;
+                        d0[0] = o[4 * h]; d0[1] = o[4 * h + 1]; d1[0] = o[4 * h + 2]; d1[1] = o[4 * h + 3];
+                        const int vi = (t * 2 + h) * 2;      // ((j*2 + pr)*2 + h)*2
+                        gacc[vi] = g32_dot2(d0, ones, gacc[vi]);         gacc[vi] = g32_dot2(d1, ones, gacc[vi]);
+                        gacc[vi + 1] = g32_dot2(d0, d0, gacc[vi + 1]);   gacc[vi + 1] = g32_dot2(d1, d1, gacc[vi + 1]);
+                    }
+                }
+            }
+        });
+        if constexpr (STATS) stats_out(gacc);
+    };
+    if (G32_EPI_PIPE) {
+        const bool full = m0 + BM <= p.M && n0 + BN <= p.N;      // (uniform)
+        if (full) { if (res) pipe(icg<1>{}, icg<1>{}); else pipe(icg<1>{}, icg<0>{}); }
+        else      { if (res) pipe(icg<0>{}, icg<1>{}); else pipe(icg<0>{}, icg<0>{}); }
+        return;
+    }
     if constexpr (!GEGLU) {
         // STATS: (sum, sum of squares) of the lane's stored values per 4-channel quad: index ((j*2 + pr)*2 + h)*2 + {0, 1}
-        constexpr int NV = STATS ? FNW * 8 : 1;
         typedef T tx2 __attribute__((ext_vector_type(2)));
         float gacc[NV];
 #pragma unroll
@@ -403,45 +571,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
                 }
             }
         }
-        // ---- GroupNorm partial sums of the stored tile (the next layer's norm): lane (l31, lh) holds NV sums over ITS row(s);
-        // rows -> wave through an LDS transpose (lane t adds value t % 32 of the 32 lanes of half t / 32: fixed order), waves ->
-        // workgroup -> one slot per (image, row tile, group).  The operand ring is dead: every wave's DMA has landed (the
-        // wait above) and the barrier below says every wave is done reading it.
-        if constexpr (STATS) {
-            static_assert(!STATS || NV == 32, "one value per lane and half: FNW == 4");
-            if (p.gn_part) {
-                constexpr int LST = NV + 4;                   // lane stride in floats: 16-byte writes of 16 lanes hit 16 distinct bank quads
-                float* st = (float*)i2i_smem;                 // [NW][64][LST]
-                float* st2 = st + NW * 64 * LST;              // [NW][32 quads][2]
-                lds_barrier();
-#pragma unroll
-                for (int v = 0; v < NV; v += 4)
-                    *(f32x4*)(st + (wave * 64 + lane) * LST + v) = f32x4{gacc[v], gacc[v + 1], gacc[v + 2], gacc[v + 3]};
-                lds_barrier();
-                {
-                    const int half = lane >> 5, v = lane & 31;
-                    float tot = 0.f;
-                    for (int l = 0; l < 32; ++l) tot += st[(wave * 64 + half * 32 + l) * LST + v];
-                    const int jpr = v >> 2, h = (v >> 1) & 1, sq = v & 1;        // v = ((j*2 + pr)*2 + h)*2 + sq
-                    const int quad = jpr * 4 + half * 2 + h;                      // column quad of the tile: j*8 + pr*4 + lh*2 + h
-                    st2[(wave * 32 + quad) * 2 + sq] = tot;
-                }
-                lds_barrier();
-                const int groups = p.gn_part_groups, cpg = p.N / groups, ng_tile = BN / cpg;
-                const int g = n0 / cpg + tid;
-                if (tid < ng_tile && g < groups) {
-                    const int q0 = (tid * cpg) >> 2, nq = cpg >> 2;
-                    float S = 0.f, Q = 0.f;
-                    for (int w = 0; w < NW; ++w)
-                        for (int q = q0; q < q0 + nq; ++q) { S += st2[(w * 32 + q) * 2]; Q += st2[(w * 32 + q) * 2 + 1]; }
-                    const int hw = p.ho * p.wo, parts = hw / BM;
-                    const int img = m0 / hw, part = (m0 - img * hw) / BM;
-                    float* o2 = p.gn_part + (((int64_t)img * parts + part) * groups + g) * 2;
-                    o2[0] = S;
-                    o2[1] = Q;
-                }
-            }
-        }
+        if constexpr (STATS) stats_out(gacc);
     } else {
         // GEGLU: weight rows (and bias) are interleaved per 32 as [16 value rows | 16 gate rows] (packer.geglu_linear), so a
         // fragment's registers 0..7 are values and 8..15 the gates of the SAME 16 output columns: out = value * gelu(gate),
