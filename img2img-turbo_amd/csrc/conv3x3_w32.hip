@@ -83,6 +83,17 @@ __device__ __forceinline__ float acc_rd(float a) {
 }
 #endif
 
+// 0.0f written into an AGPR here and now (see the prologue)
+#ifdef I2I_EMU
+__device__ __forceinline__ float acc_zero() { return 0.f; }
+#else
+__device__ __forceinline__ float acc_zero() {
+    float a;
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(a));
+    return a;
+}
+#endif
+
 // c + a.x*b.x + a.y*b.y in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -180,7 +191,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     const T* __restrict__ a1 = (const T*)p.a1;
     const int cin = p.c0 + p.c1;
     const T* __restrict__ bw = (const T*)p.b + (SUBPIX ? (int64_t)(pa * 2 + pb) * p.N * p.ldb : 0);
-    const int hin_up = SUBPIX ? p.hin : (p.up_h ? p.up_h : (p.hin << p.ups)), win_up = SUBPIX ? p.win : (p.up_w ? p.up_w : (p.win << p.ups));
+    // (the tiles walk the SOURCE plane in both forms: the plain form takes no upsampled source -- the planner sends Upsample2D to the
+    // sub-pixel form and index-map sizes to the halo conv --, so a halo pixel's address is two integer operations, not up_src()'s float
+    // divisions and branches: they were 700 of the prologue's 2 900 instructions, in front of the first load)
+    const int hin_up = p.hin, win_up = p.win;
 
     // LDS map.  Halo: FOUR planes, one per k16 step (channels 16*kk .. +15 of the slab), rows of 32 bytes = 2 chunks,
     // chunk h of row r at physical chunk h ^ ((r>>3)&1): a fragment read (32 consecutive rows, lanes 0-31 chunk 0,
@@ -207,8 +221,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int iy = ty0 + hy + pa - 1, ix = tx0 + hx + pb - 1;      // coordinates in the (upsampled) input plane; SUBPIX: source plane
             if ((unsigned)iy < (unsigned)hin_up && (unsigned)ix < (unsigned)win_up) {
-                pix = SUBPIX ? (unsigned)(iy * p.win + ix)
-                             : (unsigned)(up_src(iy, p.hin, hin_up, p.ups) * p.win + up_src(ix, p.win, win_up, p.ups));
+                pix = (unsigned)(iy * p.win + ix);
                 pad = false;
             }
         }
@@ -319,12 +332,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     };
 
     f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- prologue: weights of steps 0..2, GN constants of every input channel, bias, halo of slab 0
 #pragma unroll
@@ -349,8 +356,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         }
     }
 #pragma unroll
-    for (int j = 0; j < HPT; ++j) halo_load(0, j, false);
-    wait_vmcnt<0>();
+    for (int j = 0; j < HPT; ++j) halo_load(0, j, true);
+    // Hidden loads with hand-counted waits, as in the K loop (beside the DMAs hipcc waits vmcnt(0) for a load it can see).  The 256
+    // accumulator writes go into their shadow (acc_zero(): volatile, so they stay in front of the wait; as plain constants hipcc
+    // re-materialises them in front of the first MFMA, after the second barrier).  The wait below lets exactly the HPT halo loads stay in flight -- every DMA (weights of steps
+    // 0..2, GroupNorm constants, bias) is older --, and the transform takes the chunks in arrival order, two at a time.
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = K2 ? 0.f : acc_zero();      // (second-contraction kernels: pinned AGPR writes cost them 230-280 spilled registers)
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<HPT>();
     lds_barrier();
     load_ssr(0);
     if constexpr (GN) {
@@ -358,6 +376,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
         // form is a dependent chain of ~9 instructions per element, and nothing else issues on this SIMD while it waits)
         static_for_w<(HPT + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
             constexpr int j0 = 2 * decltype(pc)::value, j1 = j0 + 1;
+            wait_vmcnt<(HPT - j0 - 2 > 0 ? HPT - j0 - 2 : 0)>();
+            reg_fence(rh[j0]);
+            if constexpr (j1 < HPT) reg_fence(rh[j1]);
             static_for_w<16>([&](auto mc) __attribute__((always_inline)) {
                 xform_piece(icw<j0>{}, mc, icw<0>{});
                 if constexpr (j1 < HPT) xform_piece(icw<j1>{}, mc, icw<1>{});
@@ -367,8 +388,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
             if constexpr (j1 < HPT) halo_store(j1);
         });
     } else {
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) { halo_xform(j); halo_store(j); }
+        static_for_w<HPT>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            wait_vmcnt<HPT - j - 1>();
+            reg_fence(rh[j]);
+            halo_xform(j);
+            halo_store(j);
+        });
     }
     lds_barrier();
 
@@ -925,7 +951,7 @@ int w32_launch_f16_42(const i2i_igemm_params& p, hipStream_t s) { return launch_
 
 #if !defined(W32_PART) || W32_PART == 0
 namespace i2i {
-// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 (optionally over a nearest-upsampled source), 64-aligned channel
+// Eligibility: 16-bit dtype, 3x3 stride 1 pad 1 over a source of the output's size, 64-aligned channel
 // counts, plane at least one 8 x 32 tile, at least 128 output channels, 16-byte epilogue vectors, GroupNorm only
 // together with SiLU; the sub-pixel upsampler form on source planes of at least 8 x 32.
 bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
@@ -940,8 +966,7 @@ bool conv3x3_w32_eligible(const i2i_igemm_params& p, int dtype) {
         return p.win >= W32_TW && p.hin >= 8 && p.ho == 2 * p.hin && p.wo == 2 * p.win;
     }
     if (p.wo < W32_TW || p.ho < 8) return false;
-    if (p.ho != (p.up_h ? p.up_h : (p.hin << p.ups)) || p.wo != (p.up_w ? p.up_w : (p.win << p.ups))) return false;
-    if ((p.up_h || p.up_w) && p.ups != 1) return false;
+    if (p.ups || p.up_h || p.up_w || p.ho != p.hin || p.wo != p.win) return false;      // (upsampled sources: the sub-pixel form above, or the halo conv)
     if (p.gn_ss && p.act != 1) return false;
     if (!p.gn_ss && p.act) return false;
     return true;

@@ -36,6 +36,16 @@ __device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) { return _
 __device__ __forceinline__ f32x16 mma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <int V> struct icg { static constexpr int value = V; };
+// 0.0f written into an accumulator register here and now (volatile: stays where it is written)
+#ifdef I2I_EMU
+__device__ __forceinline__ float g32_acc_zero() { return 0.f; }
+#else
+__device__ __forceinline__ float g32_acc_zero() {
+    float a;
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(a));
+    return a;
+}
+#endif
 template <int N, class F> __device__ __forceinline__ void static_for_g(F&& f) {
     if constexpr (N > 0) {
         static_for_g<N - 1>(f);
@@ -226,13 +236,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
         for (int q = 0; q < QA; ++q) a_voff[q] = a_row[q] * ldb2 + sch16;
     };
 
-    f32x16 acc[FMW][FNW];
-#pragma unroll
-    for (int i = 0; i < FMW; ++i)
-#pragma unroll
-        for (int j = 0; j < FNW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 acc[FMW][FNW];                                 // (zeroed in the shadow of the prologue's DMAs, below)
 
     // ---- per-lane fragment read offsets: row l31 of a 32-row fragment, chunk (2*kk + lh) ^ swz(l31); fragment i / j and the
     // ring slot are added, the k16 step enters as ^ (kk << 5)
@@ -285,6 +289,14 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
         if (t < RING - 1) static_for_g<OPB>([&](auto qc) __attribute__((always_inline)) { dma_piece(qc); });
         else static_for_g<win_n(0)>([&](auto qc) __attribute__((always_inline)) { dma_piece(qc); });
     }
+    // the accumulator writes, pinned in front of the wait (as plain constants hipcc re-materialises them behind the barrier, in front of
+    // the first MFMA: 160 instructions of a tile whose K loop may be 200 MFMAs)
+#pragma unroll
+    for (int i = 0; i < FMW; ++i)
+#pragma unroll
+        for (int j = 0; j < FNW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = g32_acc_zero();
     wait_vmcnt<(RING - 2) * OPB + win_n(0)>();
     lds_barrier();
 #pragma unroll
