@@ -48,7 +48,10 @@ def main():
             os.environ.pop(k, None)
         os.environ.update(env)
         touched |= set(env)
-        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype)
+        # (an arm may also name another build of the library: I2I_LIB=<path> -- csrc/build.py --tag ...)
+        from img2img_turbo_amd import _capi
+        lib = _capi.Library(env["I2I_LIB"]) if env.get("I2I_LIB") else None
+        model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype, lib=lib)
         plan = model.get_plan(a.batch, a.size, a.size)
         model.stage(plan, x.to(dev), cap.to(dev), eps.to(dev), None)
         for _ in range(3):

@@ -112,6 +112,9 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }    
 #endif
 
 constexpr int W32_TW = 32, W32_CK = 64, W32_RING = 3, W32_MAX_CIN = 1024;
+// weight ring of the sub-pixel form: 4 taps per slab, two stages (a four-deep ring on the 128-channel tile measured the same:
+// profiles/r5k_subpix_ring_and_tile.log)
+constexpr int w32_spx_ring(int) { return 2; }
 constexpr int SPX_ROW_CHUNKS = W32_TW / 4;              // row layout of the epilogue: a lane owns chunk c16 of pixels p4, p4 + 4, ...: 8 per 32-pixel row
 // bytes of one k16 plane of the halo image: rows of 32 bytes, padded to 32 (mod 128)
 constexpr int w32_plane_px(int halo_px) { return ((halo_px * 32 + 127) / 128) * 128 + 32; }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv3x3_w32_kernel
     static_assert(!SUBPIX || (!GN && !RES), "");
     static_assert(!K2 || !RES, "a launch with a second contraction has no residual (the contraction replaces it)");
     constexpr int KS = SUBPIX ? 2 : 3, NPAR = SUBPIX ? 4 : 1;
-    constexpr int TW = W32_TW, CK = W32_CK, RING = SUBPIX ? 2 : W32_RING, NTAPS = KS * KS;
+    constexpr int TW = W32_TW, CK = W32_CK, RING = SUBPIX ? w32_spx_ring(BN) : W32_RING, NTAPS = KS * KS;
     static_assert(NTAPS % RING == 0, "the ring slot of a tap is a compile-time constant");
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int HW2 = TW + KS - 1, HALO = (TH + KS - 1) * HW2;
@@ -893,7 +896,7 @@ int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
     const size_t smem = 4 * w32_plane(TH) + 1024 + W32_RING * BN * 128 + (gn ? (size_t)(p.c0 + p.c1) * 8 : 0) + BN * 4;
     const dim3 g(tiles), b(WM * WN * 64);
     if (p.subpix) {
-        const size_t smem_sp = 4 * w32_plane(TH, true) + 1024 + 2 * BN * 128 + BN * 4;        // 2-deep weight ring
+        const size_t smem_sp = 4 * w32_plane(TH, true) + 1024 + w32_spx_ring(BN) * BN * 128 + BN * 4;
         if (p.k2_a) hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true, true>), g, b, smem_sp, s, p);
         else hipLaunchKernelGGL((conv3x3_w32_kernel<T, TH, BN, WM, WN, false, false, true, false>), g, b, smem_sp, s, p);
         return i2i::check_launch("conv3x3_w32<SUBPIX>");
@@ -917,7 +920,10 @@ int launch_w32(const i2i_igemm_params& p, hipStream_t s) {
 // profiles/r3_w32_ab_nogn.log.  Removed.)
 int w32_cfg(const i2i_igemm_params& p) {
     int cfg = p.tile;
-    if (cfg == 0 || cfg == 40) cfg = (p.N % 256 == 0) ? 41 : 42;
+#ifndef W32_AUTO_41
+#define W32_AUTO_41 1      // (A/B builds: 0 = the 16 x 32 x 128 tile everywhere; 2 = everywhere but the sub-pixel form)
+#endif
+    if (cfg == 0 || cfg == 40) cfg = (p.N % 256 == 0 && (W32_AUTO_41 == 1 || (W32_AUTO_41 == 2 && !p.subpix))) ? 41 : 42;
     return cfg;
 }
 void w32_cfg_geometry(int cfg, int* th, int* bn, int* wtn) {
