@@ -54,3 +54,6 @@ for shape in "unet lin 1280->320 T4096" "unet 960->320@64 gn"; do
   python tools/pmc_summary.py $(find $d -name "*counter_collection.csv" | sort | tr '\n' ' ') gemm_w32_kernel >> $O/${TAG}_pmc_gemm_w32_summary.txt 2>&1
 done
 cat $O/${TAG}_pmc_gemm_w32_summary.txt
+# 8. socket power / shader clock while the dominant launches run back to back, random vs zero operands (benchmarks/power_probe.py)
+timeout 200 python benchmarks/power_probe.py --out $O/${TAG}_power_probe.json 2>&1 | grep -v "amdgpu.ids\|smi sample" | cut -c1-220 > $O/${TAG}_power_probe.log
+cat $O/${TAG}_power_probe.log

@@ -42,6 +42,15 @@ def hwmon_files():
     return out
 
 
+def smi_numbers(raw):
+    """(socket power W, mean gfx clock MHz over the XCDs) out of one `amd-smi metric --power --clock --json` reading (text search: the
+    stored reading may be truncated)."""
+    import re
+    m = re.search(r'"socket_power":\s*\{\s*"value":\s*(\d+)', raw)
+    c = [int(v) for v in re.findall(r'"gfx_\d+":\s*\{\s*"clk":\s*\{\s*"value":\s*(\d+)', raw)]
+    return (int(m.group(1)) if m else None), (round(sum(c) / len(c)) if c else None)
+
+
 def smi_once():
     """One slow sample through the command-line tools (whatever this image has); returns a short dict of strings."""
     for cmd in (["amd-smi", "metric", "-g", "0", "--power", "--clock", "--json"], ["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--json"]):
@@ -146,7 +155,7 @@ def main():
             t_med, t_first = tail[len(tail) // 2], sorted(ms[:max(3, k // 4)])[max(1, k // 8)]
             rec = {"shape": name, "fill": fill, "launches": n, "ms_median_after_ramp": t_med, "ms_first_launches": t_first, "tflops": fl / t_med / 1e9,
                    "power_w": stats(smp.rows, "power1_average", 1e-6) or stats(smp.rows, "power1_input", 1e-6),
-                   "sclk_mhz": stats(smp.rows, "freq1_input", 1e-6), "smi": smp.smi_rows[-2:]}
+                   "sclk_mhz": stats(smp.rows, "freq1_input", 1e-6), "smi": smp.smi_rows[-2:]}      # (hwmon of card0 may be another device: amd-smi is the reading)
             res.setdefault("runs", []).append(rec)
             pw, ck = rec["power_w"], rec["sclk_mhz"]
             print("%-30s %-5s  %6d launches  %.4f ms (first launches %.4f)  %7.1f TF   power %s W   sclk %s MHz" % (
@@ -154,7 +163,9 @@ def main():
                 ("%.0f (%.0f..%.0f)" % (pw["mean"], pw["min"], pw["max"])) if pw else "n/a",
                 ("%.0f (%.0f..%.0f)" % (ck["mean"], ck["min"], ck["max"])) if ck else "n/a"), flush=True)
             if smp.smi_rows:
-                print("   smi:", smp.smi_rows[-1]["raw"][:1200].replace("\n", " "), flush=True)
+                nums = [smi_numbers(r["raw"]) for r in smp.smi_rows]
+                rec["smi_socket_w"], rec["smi_gfx_mhz"] = [n[0] for n in nums], [n[1] for n in nums]
+                print("   amd-smi: socket power %s W   gfx clock %s MHz (mean over the XCDs; one reading per second)" % (rec["smi_socket_w"], rec["smi_gfx_mhz"]), flush=True)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
