@@ -519,6 +519,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void igemm_dma_kernel(const i2i_
 }
 
 // split-K reduce: out = epilogue(alpha * sum_s ws[s][m][n]); fixed summation order (deterministic).
+// Every load of a thread is in flight before the first is used: the slabs eight at a time (the adds keep the slice order, so the bits
+// do not depend on the batching), the bias quad and the residual quad with them.  The first form -- one slab load per loop iteration,
+// bias and residual behind per-element branches after the sum -- was a chain of `splitk` + 2 dependent L2 / HBM round trips: 6.75 us per
+// launch, 151 launches in a batch-1 forward.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const i2i_igemm_params p) {
     const int64_t total = (int64_t)p.M * p.N;
@@ -527,15 +531,65 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const i2i_igemm_para
     const float* ws = (const float*)p.ws;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     const bool vec = (p.N & 3) == 0;
-    for (int s = 0; s < p.splitk; ++s) {
-        if (vec) {
-            const f32x4 t = *(const f32x4*)(ws + (int64_t)s * total + e0);
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    const bool bvec_ok = p.bias_mode != 1 || (((uintptr_t)p.bias & 15) == 0);
+    const bool rvec_ok = !p.res || ((p.ldr & 3) == 0 && (((uintptr_t)p.res & (4 * sizeof(T) - 1)) == 0));
+    if (vec && bvec_ok && rvec_ok) {
+        // a quad lies in one row: m, n .. n + 3.  Bias and residual are loaded UNCONDITIONALLY (from the quad's own slab address when
+        // the launch has none: valid, aligned, unused) -- a load behind a runtime branch is waited for at the join, in front of the slabs
+        const int m = (int)(e0 / p.N), n = (int)(e0 - (int64_t)m * p.N);
+        const f32x4 bq = *(const f32x4*)(p.bias_mode == 1 ? p.bias + n : ws + e0);
+        const float bm = *(p.bias_mode == 2 ? p.bias + m : ws + e0);
+        const tx4 r4 = *(const tx4*)(p.res ? (const T*)p.res + (int64_t)m * p.ldr + n : (const T*)(ws + e0));
+        int s = 0;
+        for (; s + 8 <= p.splitk; s += 8) {
+            f32x4 t[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += t[r];
-        } else {
+            for (int k = 0; k < 8; ++k) t[k] = *(const f32x4*)(ws + (int64_t)(s + k) * total + e0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (e0 + r < total) v[r] += ws[(int64_t)s * total + e0 + r];
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += t[k][r];
         }
+        if (s < p.splitk) {
+            f32x4 t[8];      // the last batch: slices past the end re-read the last one and are not added
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = *(const f32x4*)(ws + (int64_t)(s + k < p.splitk ? s + k : p.splitk - 1) * total + e0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s + k < p.splitk) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += t[k][r];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = p.alpha * v[r];
+            if (p.bias_mode == 1) t += bq[r];
+            else if (p.bias_mode == 2) t += bm;
+            t = act_out_f(t, p.act_out);
+            if (p.res) t += to_f32<T>(r4[r]);
+            v[r] = t;
+        }
+        if (p.out_f32) {
+            if ((p.ldc & 3) == 0 && (((uintptr_t)p.c & 15) == 0)) *(f32x4*)((float*)p.c + (int64_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ((float*)p.c)[(int64_t)m * p.ldc + n + r] = v[r];
+        } else {
+            tx4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+            if ((p.ldc & 3) == 0 && (((uintptr_t)p.c & (4 * sizeof(T) - 1)) == 0)) *(tx4*)((T*)p.c + (int64_t)m * p.ldc + n) = o;
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ((T*)p.c)[(int64_t)m * p.ldc + n + r] = o[r];
+        }
+        return;
+    }
+    for (int s = 0; s < p.splitk; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (e0 + r < total) v[r] += ws[(int64_t)s * total + e0 + r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
