@@ -85,6 +85,9 @@ def test_layernorm(emu_lib, dtype):
     oc.check_layernorm(emu_lib, "cpu", dtype)
     oc.check_layernorm(emu_lib, "cpu", dtype, c=1280, rows=5)
     oc.check_layernorm(emu_lib, "cpu", dtype, c=64, rows=4)
+    oc.check_layernorm(emu_lib, "cpu", dtype, c=640, rows=7)          # two chunks per lane: a wave takes two rows (one ragged)
+    oc.check_layernorm(emu_lib, "cpu", dtype, c=1024, rows=3, seed=2)
+    oc.check_layernorm(emu_lib, "cpu", dtype, c=320, rows=33, seed=3)  # four rows per wave, 16 per workgroup: a ragged last workgroup
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -52,6 +52,9 @@ def test_norms(gpu_lib, dtype):
     oc.check_gn_stats(gpu_lib, "cuda", dtype, n=1, c0=512, h=64, w=64, groups=32, nparts=32, sliced=True)
     oc.check_layernorm(gpu_lib, "cuda", dtype, rows=1000, c=1280)
     oc.check_layernorm(gpu_lib, "cuda", dtype, rows=77, c=320)
+    oc.check_layernorm(gpu_lib, "cuda", dtype, rows=4099, c=320, seed=1)    # four rows per wave, ragged last wave
+    oc.check_layernorm(gpu_lib, "cuda", dtype, rows=1031, c=640, seed=2)    # two rows per wave
+    oc.check_layernorm(gpu_lib, "cuda", dtype, rows=77, c=1024, seed=3)     # the text tower's width
     oc.check_softmax(gpu_lib, "cuda", dtype, rows=500, cols=1024, ldp=1024)
     oc.check_softmax(gpu_lib, "cuda", dtype, rows=500, cols=77, ldp=80)
 
