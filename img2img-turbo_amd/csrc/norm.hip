@@ -253,55 +253,64 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const i2i_gn_apply_params
 }
 
 constexpr int LN_JMAX = 4;   // 4*64*8 = 2048 channels per row max
-template <typename T>
+// One wave per row, a lane owns chunks lane, lane + 64, ... (8 channels each; J = chunks per lane: 1 up to 512 channels, 2 up to 1024, 4 up
+// to 2048).  ALL of a lane's row loads and its gamma / beta quads are requested before the first reduction: behind `if (chunk < cc)` each
+// load was waited for at its join and gamma / beta were only requested after the second reduction -- 3 to 6 dependent round trips in a
+// kernel of ~10 us.  (Lanes past the row read chunk 0 and drop it.)  Arithmetic and its order are unchanged.
+// (Several rows per wave -- more loads per lane in flight, fewer waves -- measured SLOWER: profiles/r5p_ab_layernorm_rows_per_wave_negative.log.)
+template <typename T, int J>
 __global__ __launch_bounds__(256) void layernorm_kernel(const i2i_layernorm_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
-    constexpr int EPC = Elem<T>::EPC;
+    constexpr int EPC = Elem<T>::EPC, H = 8 / EPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.rows) return;
     const int cc = p.c >> 3;
     const T* x = (const T*)p.x + (int64_t)row * p.ldx;
-    float v[LN_JMAX][8];
+    chunk_t raw[J][H];
+    f32x4 gq[J][2], bq[J][2];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int cp = lane + j * 64, cpc = cp < cc ? cp : 0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) raw[j][h] = *(const chunk_t*)(x + (cpc << 3) + h * EPC);
+        gq[j][0] = *(const f32x4*)(p.gamma + (cpc << 3)); gq[j][1] = *(const f32x4*)(p.gamma + (cpc << 3) + 4);
+        bq[j][0] = *(const f32x4*)(p.beta + (cpc << 3));  bq[j][1] = *(const f32x4*)(p.beta + (cpc << 3) + 4);
+    }
+    float v[J][8];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_JMAX; ++j) {
-        const int cp = lane + j * 64;
-        if (cp < cc) {
+    for (int j = 0; j < J; ++j) {
+        const bool ok = lane + j * 64 < cc;
 #pragma unroll
-            for (int h = 0; h < 8 / EPC; ++h) {
-                const chunk_t c = *(const chunk_t*)(x + (cp << 3) + h * EPC);
+        for (int h = 0; h < H; ++h)
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { v[j][h * EPC + e] = to_f32<T>(c[e]); sum += v[j][h * EPC + e]; }
+            for (int e = 0; e < EPC; ++e) {
+                v[j][h * EPC + e] = ok ? to_f32<T>(raw[j][h][e]) : 0.f;
+                if (ok) sum += v[j][h * EPC + e];
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
-        }
     }
     const float mu = wave_sum(sum) / (float)p.c;
     float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_JMAX; ++j) {
-        const int cp = lane + j * 64;
-        if (cp < cc) {
+    for (int j = 0; j < J; ++j)
+        if (lane + j * 64 < cc) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; sq += d * d; }
         }
-    }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.c + p.eps);
     T* y = (T*)p.y + (int64_t)row * p.ldy;
 #pragma unroll
-    for (int j = 0; j < LN_JMAX; ++j) {
+    for (int j = 0; j < J; ++j) {
         const int cp = lane + j * 64;
         if (cp < cc) {
 #pragma unroll
-            for (int h = 0; h < 8 / EPC; ++h) {
+            for (int h = 0; h < H; ++h) {
                 chunk_t c;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const int ch = (cp << 3) + h * EPC + e;
-                    c[e] = from_f32<T>((v[j][h * EPC + e] - mu) * rstd * p.gamma[ch] + p.beta[ch]);
+                    const int q = h * EPC + e;
+                    c[e] = from_f32<T>((v[j][q] - mu) * rstd * gq[j][q >> 2][q & 3] + bq[j][q >> 2][q & 3]);
                 }
                 *(chunk_t*)(y + (cp << 3) + h * EPC) = c;
             }
@@ -665,14 +674,23 @@ extern "C" int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* strea
 extern "C" int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream) {
     if (!p || !p->x || !p->y || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: null pointer");
     if (p->c % 8 || p->c > LN_JMAX * 64 * 8 || p->ldx % 8 || p->ldy % 8) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: bad c=%d", p->c);
+    if (((uintptr_t)p->gamma | (uintptr_t)p->beta) & 15) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: gamma / beta must be 16-byte aligned");
     const unsigned grid = (unsigned)((p->rows + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+    const int cc = p->c >> 3, jj = cc <= 64 ? 1 : (cc <= 128 ? 2 : 4);      // chunks per lane
+#define I2I_LN_LAUNCH(T)                                                                                             \
+    do {                                                                                                              \
+        if (jj == 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *p);                   \
+        else if (jj == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(grid), dim3(256), 0, s, *p);              \
+        else hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *p);                           \
+    } while (0)
     switch (dtype) {
-        case I2I_F32: hipLaunchKernelGGL((layernorm_kernel<float>), dim3(grid), dim3(256), 0, s, *p); break;
-        case I2I_BF16: hipLaunchKernelGGL((layernorm_kernel<__bf16>), dim3(grid), dim3(256), 0, s, *p); break;
-        case I2I_F16: hipLaunchKernelGGL((layernorm_kernel<_Float16>), dim3(grid), dim3(256), 0, s, *p); break;
+        case I2I_F32: I2I_LN_LAUNCH(float); break;
+        case I2I_BF16: I2I_LN_LAUNCH(__bf16); break;
+        case I2I_F16: I2I_LN_LAUNCH(_Float16); break;
         default: return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: bad dtype");
     }
+#undef I2I_LN_LAUNCH
     return i2i::check_launch("layernorm");
 }
 
