@@ -189,10 +189,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
     float* red = rstd + gpb;                      // [nsl][gpb][2] slice partials
     const int nsl = 256 / gpb;
     const int gl = tid % gpb, sl = tid / gpb;
+    // gamma / beta of this thread's first channel, requested with the partial sums (at their use below they were one more dependent round
+    // trip behind three barriers, in a kernel of ~5 us)
+    const int cpre = g0 * cpg + tid;
+    const bool pre_ok = cpre < (g0 + gpb) * cpg;
+    const float gam0 = p.gamma[pre_ok ? cpre : 0], bet0 = p.beta[pre_ok ? cpre : 0];
     if (sl < nsl) {
         float S = 0.f, Q = 0.f;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll 4
+#pragma unroll 8
         for (int part = sl; part < p.nparts; part += nsl) {
             const f32x2 v = *(const f32x2*)(p.partial + (((int64_t)img * p.nparts + part) * p.groups + g0 + gl) * 2);
             S += v[0];
@@ -219,12 +224,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const i2i_gn_stats_par
         if (tid == 0) { mean[g] = mu; rstd[g] = rsqrtf(var + p.eps); }
     }
     __syncthreads();
-    for (int c = g0 * cpg + tid; c < (g0 + gpb) * cpg; c += 256) {
+    for (int c = cpre; c < (g0 + gpb) * cpg; c += 256) {
         const int g = c / cpg - g0;
-        const float sc = rstd[g] * p.gamma[c];
+        const float sc = rstd[g] * (c == cpre ? gam0 : p.gamma[c]);
         float* o = p.ss + ((int64_t)img * ct + c) * 2;
         o[0] = sc;
-        o[1] = p.beta[c] - mean[g] * sc;
+        o[1] = (c == cpre ? bet0 : p.beta[c]) - mean[g] * sc;
     }
 }
 
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
     const int tid = threadIdx.x, img = blockIdx.x, g0 = blockIdx.y * gpb;
     const int ct = p.c0 + p.c1, cpg = ct / p.groups;
     const int nch = gpb * cpg, c_first = g0 * cpg;          // this block's channel range (multiple of 8: host check)
+    const float gam0 = p.gamma[c_first + (tid < nch ? tid : 0)], bet0 = p.beta[c_first + (tid < nch ? tid : 0)];      // (requested up front: see gn_finalize_kernel)
     const int U = nch >> 3, ppb = 256 / U;
     const int unit = tid % U, prow = tid / U;
     float s[8], q[8];
@@ -413,10 +419,10 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const i2i_gn_stats_
     __syncthreads();
     for (int c = tid; c < nch; c += 256) {
         const int g = c / cpg, cc = c_first + c;
-        const float sc = gst[2 * g + 1] * p.gamma[cc];
+        const float sc = gst[2 * g + 1] * (c == tid ? gam0 : p.gamma[cc]);
         float* o = p.ss + ((int64_t)img * ct + cc) * 2;
         o[0] = sc;
-        o[1] = p.beta[cc] - gst[2 * g] * sc;
+        o[1] = (c == tid ? bet0 : p.beta[cc]) - gst[2 * g] * sc;
     }
 }
 
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(256) void gn_stats_sliced_kernel(const i2i_gn_stats
     const int tid = threadIdx.x, img = blockIdx.x, set = blockIdx.y, sl = blockIdx.z, g0 = set * gpb;
     const int ct = p.c0 + p.c1, cpg = ct / p.groups, nsets = p.groups / gpb;
     const int nch = gpb * cpg, c_first = g0 * cpg;
+    const float gam0 = p.gamma[c_first + (tid < nch ? tid : 0)], bet0 = p.beta[c_first + (tid < nch ? tid : 0)];      // (requested up front: see gn_finalize_kernel)
     const int U = nch >> 3, ppb = 256 / U;
     const int unit = tid % U, prow = tid / U;
     const int per = (p.hw + S - 1) / S, px_lo = sl * per, px_hi = px_lo + per < p.hw ? px_lo + per : p.hw;
@@ -539,10 +546,10 @@ __global__ __launch_bounds__(256) void gn_stats_sliced_kernel(const i2i_gn_stats
     __syncthreads();
     for (int c = tid; c < nch; c += 256) {
         const int g = c / cpg, cc = c_first + c;
-        const float sc = gst[2 * g + 1] * p.gamma[cc];
+        const float sc = gst[2 * g + 1] * (c == tid ? gam0 : p.gamma[cc]);
         float* o = p.ss + ((int64_t)img * ct + cc) * 2;
         o[0] = sc;
-        o[1] = p.beta[cc] - gst[2 * g] * sc;
+        o[1] = (c == tid ? bet0 : p.beta[cc]) - gst[2 * g] * sc;
     }
 }
 
