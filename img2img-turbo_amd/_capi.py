@@ -18,6 +18,7 @@ OP_LORA_MERGE = 12
 OP_RESIZE_U8 = 13
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+ABI_VERSION = 8          # include/i2i_turbo.h I2I_ABI_VERSION this binding was written for
 
 
 class IgemmParams(C.Structure):
@@ -116,7 +117,8 @@ _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply"
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_igemm_route", "i2i_gn_stats",
            "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
            "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8", "i2i_run", "i2i_run_timed",
-           "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy"]
+           "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy",
+           "i2i_plan_load", "i2i_plan_io", "i2i_plan_write", "i2i_plan_read", "i2i_plan_ops", "i2i_plan_run", "i2i_plan_destroy"]
 
 
 class I2IError(RuntimeError):
@@ -180,7 +182,14 @@ class Library:
         L.i2i_graph_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.i2i_graph_launch.argtypes = [vp, vp]
         L.i2i_graph_destroy.argtypes = [vp]
-        if L.i2i_abi_version() != 7:
+        L.i2i_plan_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.i2i_plan_io.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.i2i_plan_write.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.i2i_plan_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.i2i_plan_ops.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
+        L.i2i_plan_run.argtypes = [vp, vp]
+        L.i2i_plan_destroy.argtypes = [vp]
+        if L.i2i_abi_version() != ABI_VERSION:
             raise I2IError("ABI version mismatch")
         if L.i2i_sizeof_op() != C.sizeof(Op):
             raise I2IError("i2i_op layout mismatch: C %d vs ctypes %d" % (L.i2i_sizeof_op(), C.sizeof(Op)))
@@ -217,6 +226,33 @@ class Library:
 
     def graph_destroy(self, g):
         self.lib.i2i_graph_destroy(g)
+
+    # ---- plan files (include/i2i_turbo.h, csrc/plan_file.hip; written by plan_file.export_plan) ----
+    def plan_load(self, path):
+        h = vp()
+        self.check(self.lib.i2i_plan_load(str(path).encode(), C.byref(h)))
+        return h
+
+    def plan_io(self, h, name):
+        ptr, n = vp(), C.c_size_t()
+        self.check(self.lib.i2i_plan_io(h, name.encode(), C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def plan_write(self, h, name, host_tensor):
+        t = host_tensor.contiguous()
+        assert t.device.type == "cpu"
+        self.check(self.lib.i2i_plan_write(h, name.encode(), vp(t.data_ptr()), t.numel() * t.element_size()))
+
+    def plan_read(self, h, name, host_tensor):
+        assert host_tensor.device.type == "cpu" and host_tensor.is_contiguous()
+        self.check(self.lib.i2i_plan_read(h, name.encode(), vp(host_tensor.data_ptr()), host_tensor.numel() * host_tensor.element_size()))
+        return host_tensor
+
+    def plan_run(self, h, stream=0):
+        self.check(self.lib.i2i_plan_run(h, vp(stream)))
+
+    def plan_destroy(self, h):
+        self.lib.i2i_plan_destroy(h)
 
 
 class Program:

@@ -70,3 +70,25 @@ extern "C" int i2i_graph_destroy(void* graph) {
     delete g;
     return I2I_OK;
 }
+
+// ---- device memory for plan files (plan_file.hip): synchronous on purpose -- load / write / read are not on the latency path
+namespace i2i {
+void* rt_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+}
+void rt_free(void* p) { (void)hipFree(p); }
+int rt_upload(void* dst, const void* src, size_t bytes) {
+    I2I_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return I2I_OK;
+}
+int rt_download(void* dst, const void* src, size_t bytes) {
+    I2I_HIP(hipDeviceSynchronize());      // (the program may still be running on a non-blocking stream)
+    I2I_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return I2I_OK;
+}
+int rt_zero(void* dst, size_t bytes) {
+    I2I_HIP(hipMemset(dst, 0, bytes));
+    return I2I_OK;
+}
+}  // namespace i2i

@@ -1,0 +1,136 @@
+"""Plan files: save a planned forward so that a C / C++ host can run it without Python (include/i2i_turbo.h ``i2i_plan_*``,
+csrc/plan_file.hip has the file layout).
+
+    model = Pix2Pix_Turbo(weights=..., device="cuda", dtype=torch.bfloat16)
+    plan = model.get_plan(8, 512, 512)
+    export_plan(plan, "pix2pix_bs8_512.i2iplan")          # once, where Python and the checkpoints are
+
+    /* C host */  i2i_plan_load(path, &p); i2i_plan_write(p, "x", ...); "ctx"; "eps"; i2i_plan_run(p, stream); i2i_plan_read(p, "out", ...);
+
+What is saved: the op program (``plan.prog``: every launch with its tile / route decisions already taken), one buffer record per
+torch storage an op pointer refers to, and a relocation table (op, pointer field) -> (buffer, offset).  Buffers of the plan's
+recycling pool and its boundary buffers are *scratch* (size only, zero-filled at load); everything else -- packed weights with the LoRA
+merged at the current scale, norm parameters, device scalars, ticket counters -- is saved with its contents.  The boundary buffers get
+names: "x", "ctx", "eps", "noise" (stochastic plans), "out".
+
+This replaces the reference's ``model(...)`` call (src/pix2pix_turbo.py:186-219, src/cyclegan_turbo.py:241-254) for hosts that are not
+Python; the planner itself (route queries, tile choices, buffer recycling) stays in plan.py and runs once, at export.
+"""
+import bisect
+import ctypes as C
+import struct
+
+import torch
+
+from . import _capi as K
+
+MAGIC = b"I2IPLAN1"
+
+
+def _pointer_fields():
+    """{opcode: [(byte offset inside i2i_op, field name)]} for every pointer-typed member of that opcode's parameter struct."""
+    out = {}
+    u_off = K.Op.u.offset
+    for opcode, member in K._FIELD_OF.items():
+        st = dict(K._OpUnion._fields_)[member]
+        out[opcode] = [(u_off + getattr(st, name).offset, name) for name, ct in st._fields_ if ct is K.vp]
+    return out
+
+
+def _storage_key(t):
+    s = t.untyped_storage()
+    return s.data_ptr(), s.nbytes()
+
+
+def export_plan(plan, path, extra_tensors=()):
+    """Write ``plan`` (a ForwardPlan) to ``path``.  Returns a small summary dict.  The plan must not be replaying while this runs
+    (the buffers' contents are read back through torch)."""
+    prog = plan.prog
+    assert prog.array is not None, "the plan's program is not frozen"
+    # ---- every tensor the program can point into
+    named = {"x": plan.x_in, "ctx": plan.ctx, "eps": plan.eps, "out": plan.out}
+    if getattr(plan, "noise", None) is not None:
+        named["noise"] = plan.noise
+    # (the GroupNorm scratch -- partial sums, (scale, shift) tables, ticket counters -- is patched into the ops after they were recorded:
+    # plan._finish_gn_scratch; produced inside the program, zero at rest)
+    gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters")) if t is not None]
+    scratch_keys = {_storage_key(t) for t in list(plan.pool.all) + list(named.values()) + gn_scratch}
+    tensors = list(named.values()) + list(plan.pool.all) + gn_scratch + list(extra_tensors)
+    def harvest(obj, depth):                     # any other tensor the plan (or its packers) holds -- device scalars such as the LoRA /
+        if isinstance(obj, torch.Tensor):        # skip scale r: saved with contents; only storages an op points into end up in the file
+            tensors.append(obj)
+        elif isinstance(obj, (list, tuple)):
+            for t in obj:
+                harvest(t, depth)
+        elif isinstance(obj, dict):
+            for t in obj.values():
+                harvest(t, depth)
+        elif depth > 0 and hasattr(obj, "__dict__") and type(obj).__module__.startswith(__package__):
+            for t in vars(obj).values():
+                harvest(t, depth - 1)
+    for v in vars(plan).values():
+        harvest(v, 1)
+    for _, _, params, _ in prog.ops:
+        tensors += [t for t in getattr(params, "_keep", ()) if isinstance(t, torch.Tensor)]
+    storages = {}                                # (ptr, nbytes) -> a tensor that owns it
+    for t in tensors:
+        storages.setdefault(_storage_key(t), t)
+    keys = sorted(storages)                      # by address
+    starts = [k[0] for k in keys]
+
+    def locate(addr, what):
+        i = bisect.bisect_right(starts, addr) - 1
+        if i < 0 or addr >= keys[i][0] + max(keys[i][1], 1):
+            raise K.I2IError("export_plan: %s points at 0x%x, which no tensor pinned to the program owns" % (what, addr))
+        return i, addr - keys[i][0]
+
+    # ---- relocations
+    fields = _pointer_fields()
+    relocs, used = [], set()
+    for oi in range(prog.n):
+        op = prog.array[oi]
+        base = C.addressof(op)
+        for off, fname in fields[op.opcode]:
+            v = C.c_void_p.from_address(base + off).value
+            if not v:
+                continue
+            b, o = locate(v, "op %d (%s) field %s" % (oi, prog.labels[oi], fname))
+            relocs.append((oi, off, b, o))
+            used.add(b)
+    io = []
+    for name, t in named.items():
+        b, o = locate(t.data_ptr(), "boundary buffer " + name)
+        io.append((name, b, o, t.numel() * t.element_size()))
+        used.add(b)
+    # ---- compact the buffer table to the storages that are referenced
+    remap, bufs = {}, []
+    for b in sorted(used):
+        remap[b] = len(bufs)
+        k = keys[b]
+        bufs.append((k[1], 0 if k in scratch_keys else 1, storages[k]))
+    if plan.device != "cpu" and str(plan.device) != "cpu":
+        torch.cuda.synchronize()
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<6I", K.ABI_VERSION, C.sizeof(K.Op), prog.n, len(bufs), len(relocs), len(io)))
+        for nbytes, kind, _ in bufs:
+            f.write(struct.pack("<QII", nbytes, kind, 0))
+        for name, b, o, n in io:
+            f.write(struct.pack("<24sIIQQ", name.encode(), remap[b], 0, o, n))
+        for oi, off, b, o in relocs:
+            f.write(struct.pack("<IIIIQ", oi, off, remap[b], 0, o))
+        raw = bytearray(C.string_at(C.addressof(prog.array), prog.n * C.sizeof(K.Op)))
+        for oi, off, _, _ in relocs:             # pointer fields carry no meaning in the file
+            p0 = oi * C.sizeof(K.Op) + off
+            raw[p0:p0 + 8] = b"\0" * 8
+        f.write(bytes(raw))
+        data_bytes = 0
+        for nbytes, kind, t in bufs:
+            if kind != 1:
+                continue
+            s = t.untyped_storage()
+            flat = torch.empty(0, dtype=torch.uint8, device=t.device).set_(s, 0, (s.nbytes(),), (1,))
+            host = flat.cpu().numpy()
+            f.write(host.tobytes())
+            data_bytes += nbytes
+    return {"ops": prog.n, "buffers": len(bufs), "relocations": len(relocs), "data_bytes": data_bytes,
+            "scratch_bytes": sum(b[0] for b in bufs if b[1] == 0), "io": {n: sz for n, _, _, sz in io}}

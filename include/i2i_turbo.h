@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 7
+#define I2I_ABI_VERSION 8
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -293,6 +293,21 @@ int i2i_run_timed(const i2i_op* ops, int n_ops, void* stream, float* ms);
 int i2i_graph_create(const i2i_op* ops, int n_ops, void** graph_out);
 int i2i_graph_launch(void* graph, void* stream);
 int i2i_graph_destroy(void* graph);
+
+/* ---- plan files (ABI v8): a planned forward saved by the Python planner (img2img_turbo_amd/plan_file.py: the op program, every buffer
+ * its pointers refer to -- packed weights with their contents, activations as zero-filled scratch --, named input / output buffers and a
+ * relocation table), loaded and run without Python.  The whole-forward entry for C / C++ hosts: what `model(x, caption_enc=..., eps=...)`
+ * (src/pix2pix_turbo.py:186-219) is for a Python host, for one fixed (batch, size, dtype, mode).  Names of the pix2pix / CycleGAN plans:
+ * "x" (fp32 NCHW images in [-1, 1], or uint8 NHWC with the u8 boundary), "ctx" ([1 | B][77][1024] text states in the plan's dtype),
+ * "eps" (fp32 [B][4][H/8][W/8] posterior noise), "noise" (stochastic plans), "out" (images, NCHW in the plan's output dtype or uint8 NHWC).
+ * load / write / read are synchronous; run only enqueues (i2i_run); i2i_plan_ops() hands the program to i2i_graph_create(). */
+int i2i_plan_load(const char* path, void** plan_out);
+int i2i_plan_io(void* plan, const char* name, void** dev_ptr, size_t* bytes);       /* device address + size of a named buffer */
+int i2i_plan_write(void* plan, const char* name, const void* host_src, size_t bytes);
+int i2i_plan_read(void* plan, const char* name, void* host_dst, size_t bytes);     /* synchronises the device first */
+int i2i_plan_ops(void* plan, const i2i_op** ops, int* n_ops);
+int i2i_plan_run(void* plan, void* stream);
+int i2i_plan_destroy(void* plan);
 
 #ifdef __cplusplus
 }

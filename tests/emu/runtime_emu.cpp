@@ -16,3 +16,13 @@ extern "C" int i2i_graph_create(const i2i_op* ops, int n_ops, void** out) {
 }
 extern "C" int i2i_graph_launch(void* g, void* stream) { G* gg = (G*)g; return i2i_run(gg->ops.data(), (int)gg->ops.size(), stream); }
 extern "C" int i2i_graph_destroy(void* g) { delete (G*)g; return 0; }
+
+// "device" memory of plan files (csrc/plan_file.hip) is host memory here
+#include <cstdlib>
+namespace i2i {
+void* rt_alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) / 256 * 256); }
+void rt_free(void* p) { free(p); }
+int rt_upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+int rt_download(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+int rt_zero(void* dst, size_t bytes) { memset(dst, 0, bytes); return 0; }
+}  // namespace i2i

@@ -47,6 +47,69 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     assert len(sliced) >= 6 and any(p.splitk > 1 for p in sliced), len(sliced)
     err2 = (out2.float() - ref).abs().max().item()
     assert err2 < 0.25, err2
+    _check_plan_file_round_trip(emu_lib, model, x, cap, eps, nm, out)
+
+
+def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python):
+    """The whole-forward entry for hosts that are not Python (include/i2i_turbo.h i2i_plan_*): the planned forward is written to a plan
+    file, loaded by the C library into its OWN buffers (nothing of the Python plan is shared: every pointer is relocated), fed through
+    i2i_plan_write, run, read back -- and equals the Python replay bit for bit.  Also: the file refuses a truncated tail and unknown
+    buffer names."""
+    import os
+    import tempfile
+    from img2img_turbo_amd import _capi as K
+    from img2img_turbo_amd.plan_file import export_plan
+    plan = list(model._plans.values())[0]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "tiny.i2iplan")
+        info = export_plan(plan, path)
+        assert info["ops"] == plan.prog.n and set(info["io"]) == {"x", "ctx", "eps", "noise", "out"} and info["data_bytes"] > 0
+        h = lib.plan_load(path)
+        try:
+            lib.plan_write(h, "x", x.to(plan.x_in.dtype).contiguous())
+            lib.plan_write(h, "ctx", cap.to(plan.ctx.dtype).reshape(plan.ctx.shape).contiguous())
+            lib.plan_write(h, "eps", eps.to(plan.eps.dtype).contiguous())
+            lib.plan_write(h, "noise", nm.to(plan.noise.dtype).expand_as(plan.noise).contiguous())
+            lib.plan_run(h)
+            got = lib.plan_read(h, "out", torch.empty_like(plan.out, device="cpu"))
+            assert torch.equal(got.float(), out_python.float()), float((got.float() - out_python.float()).abs().max())      # (same bits: the model returns them as fp32)
+            lib.plan_run(h)          # a second run from the state the first one left (recycled buffers, ticket counters)
+            got2 = lib.plan_read(h, "out", torch.empty_like(plan.out, device="cpu"))
+            assert torch.equal(got2.float(), got.float())
+            with pytest.raises(K.I2IError):
+                lib.plan_io(h, "no_such_buffer")
+            with pytest.raises(K.I2IError):
+                lib.plan_write(h, "eps", torch.zeros(3))
+        finally:
+            lib.plan_destroy(h)
+        # the same file through a host that is not Python: examples/plan_host.c, built with gcc against the emulator library
+        import shutil
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if shutil.which("gcc"):
+            exe = os.path.join(d, "plan_host")
+            subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "plan_host.c"), "-o", exe,
+                            "-L", os.path.dirname(lib.path), "-l" + os.path.basename(lib.path)[3:-3], "-Wl,-rpath," + os.path.dirname(lib.path)], check=True)
+            files = {}
+            for name, t in (("x", x.to(plan.x_in.dtype)), ("ctx", cap.to(plan.ctx.dtype).reshape(plan.ctx.shape)), ("eps", eps.to(plan.eps.dtype)),
+                            ("noise", nm.to(plan.noise.dtype).expand_as(plan.noise))):
+                files[name] = os.path.join(d, name + ".bin")
+                with open(files[name], "wb") as f:
+                    f.write(t.contiguous().view(torch.uint8).numpy().tobytes())
+            outp = os.path.join(d, "out.bin")
+            env = dict(os.environ)
+            env.pop("I2I_EMU_ASYNC", None)
+            r = subprocess.run([exe, path, files["x"], files["ctx"], files["eps"], outp, files["noise"]], capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            with open(outp, "rb") as f:
+                host_out = torch.frombuffer(bytearray(f.read()), dtype=plan.out.dtype).reshape(plan.out.shape)
+            assert torch.equal(host_out.float(), out_python.float()), "the C host's images differ from the Python replay"
+        with open(path, "rb") as f:
+            blob = f.read()
+        with open(path, "wb") as f:
+            f.write(blob[:len(blob) - 100])
+        with pytest.raises(K.I2IError):
+            lib.plan_load(path)
 
 
 @pytest.mark.slow

@@ -121,6 +121,42 @@ def test_tiny_pix2pix_deterministic(gpu_lib, dtype):
         assert torch.equal(out, out2), "forward is not run-to-run deterministic"
 
 
+def test_plan_file_round_trip_on_the_gpu(gpu_lib, tmp_path):
+    """The whole-forward entry for hosts that are not Python (i2i_plan_*, csrc/plan_file.hip) on hardware: a planned bf16 forward is
+    exported, loaded by the C library into its own hipMalloc'ed buffers, fed through i2i_plan_write, run on the default stream and read
+    back -- the same bits as the Python replay; then the loaded program as a hipGraph (i2i_plan_ops + i2i_graph_create)."""
+    import ctypes as C
+    from img2img_turbo_amd import _capi as K
+    from img2img_turbo_amd.plan_file import export_plan
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
+    x, cap, eps, _ = make_inputs("canny", 3, 128, 64, TINY_UNET.cross_attention_dim)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16, use_graph=False)
+    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda()).cpu()
+    plan = list(model._plans.values())[0]
+    path = tmp_path / "tiny.i2iplan"
+    info = export_plan(plan, path)
+    assert info["ops"] == plan.prog.n and info["data_bytes"] > 0
+    h = gpu_lib.plan_load(path)
+    try:
+        gpu_lib.plan_write(h, "x", x.to(plan.x_in.dtype))
+        gpu_lib.plan_write(h, "ctx", cap.to(plan.ctx.dtype).reshape(plan.ctx.shape))
+        gpu_lib.plan_write(h, "eps", eps.to(plan.eps.dtype))
+        gpu_lib.plan_run(h)
+        got = gpu_lib.plan_read(h, "out", torch.empty_like(plan.out, device="cpu"))
+        assert torch.equal(got.float(), out.float()), float((got.float() - out.float()).abs().max())
+        ops, n = K.vp(), C.c_int()
+        gpu_lib.check(gpu_lib.lib.i2i_plan_ops(h, C.byref(ops), C.byref(n)))
+        g = K.vp()
+        gpu_lib.check(gpu_lib.lib.i2i_graph_create(ops, n.value, C.byref(g)))
+        for _ in range(2):
+            gpu_lib.graph_launch(g, torch.cuda.current_stream().cuda_stream)
+        got2 = gpu_lib.plan_read(h, "out", torch.empty_like(plan.out, device="cpu"))
+        gpu_lib.graph_destroy(g)
+        assert torch.equal(got2.float(), out.float())
+    finally:
+        gpu_lib.plan_destroy(h)
+
+
 def test_tiny_unfused_paths_agree(gpu_lib):
     """GN fusion off and flash attention off (materialised scores) must give the same answer."""
     mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=1)
