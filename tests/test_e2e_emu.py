@@ -50,7 +50,7 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     _check_plan_file_round_trip(emu_lib, model, x, cap, eps, nm, out)
 
 
-def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python):
+def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python, c_host=True):
     """The whole-forward entry for hosts that are not Python (include/i2i_turbo.h i2i_plan_*): the planned forward is written to a plan
     file, loaded by the C library into its OWN buffers (nothing of the Python plan is shared: every pointer is relocated), fed through
     i2i_plan_write, run, read back -- and equals the Python replay bit for bit.  Also: the file refuses a truncated tail and unknown
@@ -63,13 +63,14 @@ def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "tiny.i2iplan")
         info = export_plan(plan, path)
-        assert info["ops"] == plan.prog.n and set(info["io"]) == {"x", "ctx", "eps", "noise", "out"} and info["data_bytes"] > 0
+        assert info["ops"] == plan.prog.n and set(info["io"]) == {"x", "ctx", "eps", "out"} | ({"noise"} if nm is not None else set()) and info["data_bytes"] > 0
         h = lib.plan_load(path)
         try:
             lib.plan_write(h, "x", x.to(plan.x_in.dtype).contiguous())
             lib.plan_write(h, "ctx", cap.to(plan.ctx.dtype).reshape(plan.ctx.shape).contiguous())
             lib.plan_write(h, "eps", eps.to(plan.eps.dtype).contiguous())
-            lib.plan_write(h, "noise", nm.to(plan.noise.dtype).expand_as(plan.noise).contiguous())
+            if nm is not None:
+                lib.plan_write(h, "noise", nm.to(plan.noise.dtype).expand_as(plan.noise).contiguous())
             lib.plan_run(h)
             got = lib.plan_read(h, "out", torch.empty_like(plan.out, device="cpu"))
             assert torch.equal(got.float(), out_python.float()), float((got.float() - out_python.float()).abs().max())      # (same bits: the model returns them as fp32)
@@ -86,7 +87,7 @@ def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python):
         import shutil
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        if shutil.which("gcc"):
+        if c_host and shutil.which("gcc"):
             exe = os.path.join(d, "plan_host")
             subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "plan_host.c"), "-o", exe,
                             "-L", os.path.dirname(lib.path), "-l" + os.path.basename(lib.path)[3:-3], "-Wl,-rpath," + os.path.dirname(lib.path)], check=True)
@@ -145,6 +146,8 @@ def test_cyclegan_b2a_fp32(emu_lib):
     with pytest.raises(ValueError):
         CycleGAN_Turbo.forward_with_networks(x, "b2a", model.vae_enc, other.unet, model.vae_dec, model.sched, model.timesteps, cap)
     assert any(k.startswith("vae_b2a.") for k in model.vae_enc.state_dict()) and any(k.startswith("vae.") for k in model.vae_dec.state_dict())
+    # the CycleGAN plan (b2a: the second VAE's encoder, the first's decoder) as a plan file through the C library
+    _check_plan_file_round_trip(emu_lib, model, x, cap, eps, None, out, c_host=False)
 
 
 @pytest.mark.slow
