@@ -50,7 +50,7 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     _check_plan_file_round_trip(emu_lib, model, x, cap, eps, nm, out)
 
 
-def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python, c_host=True):
+def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python, c_host=True, plan=None):
     """The whole-forward entry for hosts that are not Python (include/i2i_turbo.h i2i_plan_*): the planned forward is written to a plan
     file, loaded by the C library into its OWN buffers (nothing of the Python plan is shared: every pointer is relocated), fed through
     i2i_plan_write, run, read back -- and equals the Python replay bit for bit.  Also: the file refuses a truncated tail and unknown
@@ -59,7 +59,7 @@ def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python, c_host=
     import tempfile
     from img2img_turbo_amd import _capi as K
     from img2img_turbo_amd.plan_file import export_plan
-    plan = list(model._plans.values())[0]
+    plan = plan or list(model._plans.values())[0]
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "tiny.i2iplan")
         info = export_plan(plan, path)
@@ -175,6 +175,8 @@ def test_pix2pix_u8_io_matches_float_io(emu_lib):
     out_u8 = model.forward_u8(img, caption_enc=cap, eps=eps)
     assert out_u8.dtype == torch.uint8 and out_u8.shape == (1, 64, 64, 3)
     assert (out_u8.int() - exp.int()).abs().max() <= 1
+    # the uint8-boundary plan as a plan file ("x" and "out" are uint8 NHWC there)
+    _check_plan_file_round_trip(emu_lib, model, img, cap, eps, None, out_u8, c_host=False, plan=[p for p in model._plans.values() if p.u8_io][0])
 
 
 @pytest.mark.slow
