@@ -134,3 +134,59 @@ def export_plan(plan, path, extra_tensors=()):
             data_bytes += nbytes
     return {"ops": prog.n, "buffers": len(bufs), "relocations": len(relocs), "data_bytes": data_bytes,
             "scratch_bytes": sum(b[0] for b in bufs if b[1] == 0), "io": {n: sz for n, _, _, sz in io}}
+
+
+def main(argv=None):
+    """python -m img2img_turbo_amd.plan_file --out pix2pix_bs8_512.i2iplan [--model pix2pix|cyclegan] [--batch 8 --size 512 --dtype bf16]
+    [--stochastic --gamma 0.4] [--direction a2b] [--u8] (--base-dir <sd-turbo snapshot> --pretrained-path <lora .pkl> | --synthetic)"""
+    import argparse
+    ap = argparse.ArgumentParser(description="export a planned forward to a plan file for C / C++ hosts (include/i2i_turbo.h i2i_plan_*)")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "cyclegan"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, nargs="+", default=[512], help="H [W]")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--stochastic", action="store_true")
+    ap.add_argument("--gamma", type=float, default=1.0, help="LoRA / skip scale r the weights are merged at (stochastic plans)")
+    ap.add_argument("--direction", default="a2b", choices=["a2b", "b2a"])
+    ap.add_argument("--u8", action="store_true", help="uint8 NHWC boundary (to_tensor / Normalize / ToPILImage inside the boundary kernels)")
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--base-dir", default=None, help="local stabilityai/sd-turbo snapshot directory")
+    ap.add_argument("--pretrained-path", default=None, help="the reference's LoRA checkpoint (.pkl)")
+    ap.add_argument("--synthetic", action="store_true", help="random-init weights of the SD-Turbo architecture (benchmarks, tests)")
+    ap.add_argument("--arch", default="sd-turbo", choices=["sd-turbo", "tiny"], help="with --synthetic: the test architecture instead of SD-Turbo's")
+    ap.add_argument("--lib", default=None, help="another build of the kernel library (tests: the CPU emulator)")
+    a = ap.parse_args(argv)
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    H, W = a.size[0], a.size[-1]
+    kw = dict(device=a.device, dtype=dt)
+    if a.lib:
+        kw["lib"] = K.Library(a.lib)
+    if a.synthetic:
+        from . import arch
+        from .synth import make_cyclegan_weights, make_pix2pix_weights
+        ua, va = (arch.TINY_UNET, arch.TINY_VAE) if a.arch == "tiny" else (arch.SD_TURBO_UNET, arch.SD_TURBO_VAE)
+        kw["weights"] = make_cyclegan_weights(ua, va) if a.model == "cyclegan" else make_pix2pix_weights(ua, va, seed=1234, sketch=a.stochastic)
+    else:
+        if not (a.base_dir and a.pretrained_path):
+            ap.error("give --base-dir and --pretrained-path (or --synthetic)")
+        kw.update(base_dir=a.base_dir, pretrained_path=a.pretrained_path)
+    if a.model == "cyclegan":
+        from .cyclegan_turbo import CycleGAN_Turbo
+        model = CycleGAN_Turbo(**kw)
+        u8 = (2.0, -1.0) if a.u8 else None          # CycleGAN callers normalise to [-1, 1] (src/inference_unpaired.py:42-44)
+        plan = model.get_plan(a.batch, H, W, direction=a.direction, u8_io=u8)
+    else:
+        from .pix2pix_turbo import Pix2Pix_Turbo
+        model = Pix2Pix_Turbo(**kw)
+        u8 = (1.0, 0.0) if a.u8 else None
+        plan = model.get_plan(a.batch, H, W, stochastic=a.stochastic, r=a.gamma, u8_io=u8)
+    if plan.before_run is not None:
+        plan.before_run(plan)                       # merge the weights at this plan's r before they are saved
+    info = export_plan(plan, a.out)
+    print("wrote %s: %d ops, %d buffers, %.2f GB of weights, %.2f GB of scratch at load; boundary buffers %s"
+          % (a.out, info["ops"], info["buffers"], info["data_bytes"] / 1e9, info["scratch_bytes"] / 1e9, info["io"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -438,6 +438,21 @@ def test_bench_two_ranks_on_the_emulator(emu_lib, extra=()):
     assert "roofline" not in rec and rec["data"].startswith("EMULATED")
 
 
+def test_plan_file_export_cli(emu_lib, tmp_path):
+    """`python -m img2img_turbo_amd.plan_file` (the exporter a user with checkpoints runs once): writes a loadable file whose boundary
+    buffers have the sizes the C host expects; here on the tiny architecture and the emulator library."""
+    from img2img_turbo_amd import plan_file
+    out = tmp_path / "cli.i2iplan"
+    plan_file.main(["--out", str(out), "--synthetic", "--arch", "tiny", "--batch", "2", "--size", "64", "72", "--dtype", "f32", "--stochastic", "--gamma", "0.4",
+                    "--device", "cpu", "--lib", emu_lib.path])
+    h = emu_lib.plan_load(out)
+    try:
+        assert emu_lib.plan_io(h, "x")[1] == 2 * 3 * 64 * 72 * 4 and emu_lib.plan_io(h, "out")[1] == 2 * 3 * 64 * 72 * 4
+        assert emu_lib.plan_io(h, "eps")[1] == 2 * 4 * 8 * 9 * 4 and emu_lib.plan_io(h, "noise")[1] == 2 * 4 * 8 * 9 * 4
+    finally:
+        emu_lib.plan_destroy(h)
+
+
 def test_product_and_oracle_twins_of_arch_and_synth_agree():
     """The product never imports oracle/, so the architecture tables and the synthetic-weight generator exist twice
     (img2img_turbo_amd/{arch,synth}.py for bench.py / smoke(), oracle/{arch,synth}.py for the checker).  They must stay the
