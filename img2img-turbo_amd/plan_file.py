@@ -45,17 +45,34 @@ def _storage_key(t):
 def export_plan(plan, path, extra_tensors=()):
     """Write ``plan`` (a ForwardPlan) to ``path``.  Returns a small summary dict.  The plan must not be replaying while this runs
     (the buffers' contents are read back through torch)."""
-    prog = plan.prog
-    assert prog.array is not None, "the plan's program is not frozen"
-    # ---- every tensor the program can point into
     named = {"x": plan.x_in, "ctx": plan.ctx, "eps": plan.eps, "out": plan.out}
     if getattr(plan, "noise", None) is not None:
         named["noise"] = plan.noise
     # (the GroupNorm scratch -- partial sums, (scale, shift) tables, ticket counters -- is patched into the ops after they were recorded:
     # plan._finish_gn_scratch; produced inside the program, zero at rest)
     gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters")) if t is not None]
-    scratch_keys = {_storage_key(t) for t in list(plan.pool.all) + list(named.values()) + gn_scratch}
-    tensors = list(named.values()) + list(plan.pool.all) + gn_scratch + list(extra_tensors)
+    return export_program(plan.prog, path, named, scratch=list(plan.pool.all) + gn_scratch, holders=[plan] + list(extra_tensors), device=plan.device)
+
+
+def export_text_plan(encoder, batch, path):
+    """The native CLIP text tower (text_encoder.ClipTextEncoder) for ``batch`` prompts as a plan file: "ids" (int64
+    [batch * 77] token ids, padded / truncated as the reference's tokenizer call does, src/pix2pix_turbo.py:190-193) -> "ctx" ([batch * 77]
+    [hidden] last hidden states in the encoder's dtype: what the generator plans take as their "ctx")."""
+    from .text_encoder import _Plan
+    tp = encoder._plans.get(batch)
+    if tp is None:
+        tp = encoder._plans[batch] = _Plan(encoder, batch)
+    return export_program(tp.prog, path, {"ids": tp.ids, "ctx": tp.out}, scratch=list(tp._keep), holders=[tp, encoder.w], device=encoder.device)
+
+
+def export_program(prog, path, named, scratch=(), holders=(), device="cpu"):
+    """The file writer behind both: ``prog`` (a frozen _capi.Program), ``named`` boundary tensors, ``scratch`` tensors whose contents need
+    not be saved (zero-filled at load, like the boundary buffers), ``holders``: objects / tensors that own anything else the ops point at."""
+    assert prog.array is not None, "the program is not frozen"
+    named = dict(named)
+    scratch_keys = {_storage_key(t) for t in list(scratch) + list(named.values())}
+    tensors = list(named.values()) + list(scratch)
+
     def harvest(obj, depth):                     # any other tensor the plan (or its packers) holds -- device scalars such as the LoRA /
         if isinstance(obj, torch.Tensor):        # skip scale r: saved with contents; only storages an op points into end up in the file
             tensors.append(obj)
@@ -68,8 +85,8 @@ def export_plan(plan, path, extra_tensors=()):
         elif depth > 0 and hasattr(obj, "__dict__") and type(obj).__module__.startswith(__package__):
             for t in vars(obj).values():
                 harvest(t, depth - 1)
-    for v in vars(plan).values():
-        harvest(v, 1)
+    for hld in holders:
+        harvest(hld, 2)
     for _, _, params, _ in prog.ops:
         tensors += [t for t in getattr(params, "_keep", ()) if isinstance(t, torch.Tensor)]
     storages = {}                                # (ptr, nbytes) -> a tensor that owns it
@@ -108,7 +125,7 @@ def export_plan(plan, path, extra_tensors=()):
         remap[b] = len(bufs)
         k = keys[b]
         bufs.append((k[1], 0 if k in scratch_keys else 1, storages[k]))
-    if plan.device != "cpu" and str(plan.device) != "cpu":
+    if str(device) != "cpu":
         torch.cuda.synchronize()
     with open(path, "wb") as f:
         f.write(MAGIC + struct.pack("<6I", K.ABI_VERSION, C.sizeof(K.Op), prog.n, len(bufs), len(relocs), len(io)))

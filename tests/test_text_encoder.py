@@ -35,6 +35,22 @@ def test_text_encoder_tiny_emu(emu_lib, dtype, tol):
     ids2 = ids.clone(); ids2[:, 50] = 7
     out2 = enc(ids2)[0].float()
     assert torch.equal(out2[:, :50], out[:, :50]) and not torch.equal(out2[:, 50:], out[:, 50:])
+    # the tower as a plan file for hosts that are not Python: "ids" -> "ctx", the same bits as the module
+    import os
+    import tempfile
+    from img2img_turbo_amd.plan_file import export_text_plan
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "clip.i2iplan")
+        info = export_text_plan(enc, 2, path)
+        assert set(info["io"]) == {"ids", "ctx"} and info["io"]["ids"] == 2 * 77 * 8
+        h = emu_lib.plan_load(path)
+        try:
+            emu_lib.plan_write(h, "ids", ids2.reshape(-1).contiguous())
+            emu_lib.plan_run(h)
+            got = emu_lib.plan_read(h, "ctx", torch.empty(2 * 77, out.shape[-1], dtype=dtype))
+        finally:
+            emu_lib.plan_destroy(h)
+        assert torch.equal(got.float().view(out2.shape), out2)
 
 
 @pytest.mark.gpu
