@@ -451,6 +451,18 @@ def test_plan_file_export_cli(emu_lib, tmp_path):
         assert emu_lib.plan_io(h, "eps")[1] == 2 * 4 * 8 * 9 * 4 and emu_lib.plan_io(h, "noise")[1] == 2 * 4 * 8 * 9 * 4
     finally:
         emu_lib.plan_destroy(h)
+    # a file of another ABI version / with a foreign header is refused with a message, not loaded
+    from img2img_turbo_amd import _capi as K
+    blob = bytearray(out.read_bytes())
+    bad_abi = bytearray(blob); bad_abi[8:12] = (K.ABI_VERSION - 1).to_bytes(4, "little")
+    for name, b in (("abi", bad_abi), ("magic", b"NOTAPLAN" + bytes(blob[8:])), ("short", bytes(blob[:20]))):
+        pth = tmp_path / (name + ".i2iplan")
+        pth.write_bytes(bytes(b))
+        with pytest.raises(K.I2IError) as e:
+            emu_lib.plan_load(pth)
+        assert ("export it again" in str(e.value)) == (name == "abi"), str(e.value)
+    with pytest.raises(K.I2IError):
+        emu_lib.plan_load(tmp_path / "does_not_exist.i2iplan")
 
 
 def test_product_and_oracle_twins_of_arch_and_synth_agree():
