@@ -228,6 +228,135 @@ def power_and_clock(plan, seconds=3.0):
             "how": "amd-smi metric --power --clock polled while the same graph replays for %.0f s after the timed region" % seconds}
 
 
+# Pool reference of the calibration loads: medians over the MI355X boxes this round's calls drew (profiles/r6_calib_boxes.json).  A bench
+# line measured on box X is normalised to this reference box family by family (see `calibrate`); raw `value` stays the headline.
+CALIB_REF = {"mfma_tflops": None, "hbm_tbytes_per_s": None, "graph_node_us": None}
+CALIB_REF_PATH = os.path.join(ROOT, "profiles", "calib_reference.json")
+if os.path.exists(CALIB_REF_PATH):
+    with open(CALIB_REF_PATH) as _f:
+        CALIB_REF.update({k: v for k, v in json.load(_f).items() if k in CALIB_REF})
+
+
+def _gpu_local_cpus(index=0):
+    """CPUs on the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return (cpus or None), txt
+    except Exception:
+        return None, None
+
+
+def _smi_json(*args):
+    import subprocess
+    try:
+        r = subprocess.run(["amd-smi"] + list(args) + ["--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        return (d.get("gpu_data") if isinstance(d, dict) else d)[0]
+    except Exception:
+        return None
+
+
+def calibrate(lib, dev, breakdown=None, ms_per_step=None, batch=None):
+    """What THIS box delivers on three elementary loads (csrc/calib.hip), outside the timed region and in about a second: a bare
+    v_mfma_f32_32x32x16_bf16 loop on random operands (one wave per SIMD: matrix pipe + power management), a 2 x 256 MiB copy stream (HBM),
+    the replay of a 1000-node hipGraph of empty kernels (launch path: microseconds per node); plus the clocks / partition / host facts
+    amd-smi and sysfs report.  The boxes of a pool differ by +-8 % on the same binary: with a reference (profiles/calib_reference.json)
+    the step time is normalised FAMILY BY FAMILY -- MFMA-bound kernel families by the MFMA ratio, HBM-bound ones by the stream ratio,
+    weighted with their measured shares of the step -- and reported as `value_normalised` beside the raw value."""
+    from img2img_turbo_amd import _capi as K
+    import ctypes as C
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {}
+    # 1. matrix pipe
+    g = torch.Generator().manual_seed(7)
+    operands = torch.randn(32768, generator=g).to(torch.bfloat16).to(dev)          # 64 KiB
+    sink = torch.zeros(65536, dtype=torch.float32, device=dev)
+    iters = 60000
+    run = lambda: lib.check(lib.lib.i2i_calib_mfma(K.BF16, iters, C.c_void_p(operands.data_ptr()), C.c_void_p(sink.data_ptr()), C.c_void_p(st)))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(12):                       # ~0.2 s back to back: the power-managed steady state, not the first cold launch
+        a, b = ev(), ev()
+        a.record(); run(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    flops = 1024.0 * iters * 8 * 32768
+    out["mfma_tflops"] = round(flops / (statistics.median(ts[4:]) * 1e-3) / 1e12, 1)
+    # 2. HBM stream
+    n = 256 << 20
+    src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    cp = lambda: lib.check(lib.lib.i2i_calib_stream(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), C.c_void_p(st)))
+    for _ in range(2):
+        cp()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        a, b = ev(), ev()
+        a.record(); cp(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    out["hbm_tbytes_per_s"] = round(2.0 * n / (statistics.median(ts) * 1e-3) / 1e12, 3)
+    del src, dst
+    # 3. launch path: 1000 empty kernels as one hipGraph
+    prog = K.Program()
+    for _ in range(1000):
+        prog.add(K.OP_NOP, K.BF16, K.NopParams())
+    prog.freeze()
+    gr = lib.graph_create(prog)
+    for _ in range(2):
+        lib.graph_launch(gr, st)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        lib.graph_launch(gr, st)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e6 / 1000)
+    lib.graph_destroy(gr)
+    out["graph_node_us"] = round(statistics.median(ts), 3)
+    # 4. what the box says about itself
+    m = _smi_json("metric", "-g", "0", "--clock", "--power")
+    if m:
+        ck = m.get("clock", {})
+        val = lambda k: (ck.get(k, {}).get("clk", {}) or {}).get("value")
+        out["clocks_mhz"] = {"mem": val("mem_0"), "fabric": val("fclk_0"), "soc": val("socclk_0"), "gfx_max": (ck.get("gfx_0", {}).get("max_clk", {}) or {}).get("value")}
+    p_ = _smi_json("partition", "-g", "0", "--current")
+    if p_:
+        pp = p_.get("partition", p_)
+        out["partition"] = {k: pp.get(k) for k in ("accelerator_type", "compute_partition", "memory", "memory_partition", "accelerator_profile_index") if k in pp} or str(pp)[:200]
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["host_cpu"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    out["host_cpus_allowed"] = len(os.sched_getaffinity(0))
+    out["gpu_local_cpulist"] = _gpu_local_cpus(torch.device(dev).index or 0)[1]
+    out["reference"] = dict(CALIB_REF)
+    if all(CALIB_REF.get(k) for k in ("mfma_tflops", "hbm_tbytes_per_s")) and breakdown and ms_per_step:
+        # time this step would take on the reference box: each family's share scaled by the ratio of the load that bounds it
+        tot = sum(v["ms"] for v in breakdown.values())
+        rm, rh = out["mfma_tflops"] / CALIB_REF["mfma_tflops"], out["hbm_tbytes_per_s"] / CALIB_REF["hbm_tbytes_per_s"]
+        scaled = sum(v["ms"] * (rm if v.get("tflops") else rh) for v in breakdown.values())
+        out["step_scale_to_reference"] = round(scaled / tot, 4)
+        out["ms_per_step_normalised"] = round(ms_per_step * scaled / tot, 3)
+        if batch:
+            out["value_normalised"] = round(batch / (ms_per_step * scaled / tot) * 1e3, 2)
+    out["how"] = ("csrc/calib.hip: 1024 waves x 60000 x 8 MFMA 32x32x16 bf16 on random operands (median of 8 back-to-back launches after 4), 2 x 256 MiB copy "
+                  "(median of 10), 1000-node empty-kernel hipGraph replay (median of 8); amd-smi / sysfs for the rest")
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -252,7 +381,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32-mode replays (images_per_s_f32 / parity_max_abs_f32) of the N = 1 line")
+    ap.add_argument("--no-modes", action="store_true", help="skip the side-by-side precision modes (mixed fp16-UNet / bf16-VAE, all-fp16) of the N = 1 bf16 line")
     ap.add_argument("--no-power", action="store_true", help="skip the amd-smi socket-power / shader-clock reading of the N = 1 line")
+    ap.add_argument("--no-calib", action="store_true", help="skip the ~1 s box calibration (MFMA loop, HBM stream, empty-graph replay) of the N = 1 line")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--serial-gather", action="store_true", help="N > 1: gather straight from the plan's output buffer on the launch stream (no overlap with the next replay)")
     ap.add_argument("--per-op", default=None, help="write the per-launch timing table (label, ms, TF) to this file")
@@ -298,6 +429,13 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a GPU"
         torch.cuda.set_device(local)
         dev = "cuda:%d" % local
+        # host threads next to the GPU: the launch path (hipGraphLaunch enqueues every node from the host) should not cross sockets
+        cpus, _ = _gpu_local_cpus(local)
+        if cpus and os.environ.get("I2I_BENCH_PIN", "1") != "0":
+            try:
+                os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+            except OSError:
+                pass
     dtype = DTYPES[a.dtype]
     ua, va = (SD_TURBO_UNET, SD_TURBO_VAE) if a.arch == "sd-turbo" else (TINY_UNET, TINY_VAE)
     B = a.batch
@@ -309,14 +447,21 @@ def main():
     t_setup = time.perf_counter()
     if world > 1:
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    # (N > 1: rank 0 synthesises, the other ranks map the same /dev/shm safetensors file -- dp.shared_weights -- instead of 8 ranks
+    # building ~950 M parameters each at the same time)
+    def build_weights():
+        if a.model == "cyclegan":
+            w_ = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
+        else:
+            w_ = make_pix2pix_weights(ua, va, seed=1234 + (4 if a.stochastic else 2), sketch=a.stochastic)
+        add_activation_offset(w_, a.activation_offset)
+        return w_
+    weights = dp.shared_weights(build_weights, rank, world, tag="bench")
+    t_weights = time.perf_counter() - t_setup
     if a.model == "cyclegan":
-        weights = make_cyclegan_weights(ua, va, seed=1234 + 3)            # r_unet = 128, r_vae = 4 (training_utils.py:140-141)
-        add_activation_offset(weights, a.activation_offset)
         model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype, **lib_kw)
         kind, cfg = "photo", 3
     else:
-        weights = make_pix2pix_weights(ua, va, seed=1234 + (4 if a.stochastic else 2), sketch=a.stochastic)
-        add_activation_offset(weights, a.activation_offset)
         model = Pix2Pix_Turbo(weights=weights, device=dev, dtype=dtype, **lib_kw)
         kind, cfg = ("sketch", 4) if a.stochastic else ("canny", 2)
     x, cap, eps, noise = synth_inputs(kind, B, a.size, ua.cross_attention_dim, va.latent_channels, 1234 + cfg + 1000 * rank)
@@ -379,7 +524,8 @@ def main():
         rec["ms_compute_per_rank"] = ms_compute                     # replay only (no gather), measured after the timed region
         rec["ms_gather"] = round(ms_per_step - max(ms_compute), 3)   # what the RCCL gather adds to the slowest rank's step
         rec["gather"] = "serial (launch stream waits)" if a.serial_gather else "double-buffered, overlapped with the next replay (side stream)"
-        rec["setup_s_per_rank"] = [round(v, 1) for v in setup_s]      # weights built + packed + uploaded + plan, concurrently on the host
+        rec["setup_s_per_rank"] = [round(v, 1) for v in setup_s]      # weights (built once on rank 0, mapped by the others) + packed + uploaded + plan
+        rec["weights_s_rank0"] = round(t_weights, 1)
     falg = F_ALG.get(a.size)
     if falg and a.arch == "sd-turbo":
         rec["e2e_mfma_frac"] = round(value / world * falg / 1e12 / PEAK_TF[a.dtype], 4)
@@ -390,6 +536,10 @@ def main():
         rec["roofline"] = roof
         rec["kernel_breakdown_ms"] = breakdown
         rec["sum_kernel_ms"] = round(tot, 3)
+        if not a.no_calib:
+            rec["calib"] = calibrate(model.lib, dev, breakdown, ms_per_step, B)
+            if rec["calib"].get("value_normalised"):
+                rec["value_normalised"] = rec["calib"]["value_normalised"]
         pc = None if a.no_power else power_and_clock(plan)
         if pc:
             rec["power"] = pc
@@ -448,6 +598,7 @@ def main():
                 rec["latency_bs%d_ms_p50" % lb] = round(statistics.median(lat), 3)
                 rec["latency_bs%d_ms_per_image_p50" % lb] = round(statistics.median(lat) / lb, 3)
         out32 = None
+        mode_out = {}          # image 0 of the batch in the other precision modes (parity against the CPU oracle below)
         if a.dtype != "f32" and not a.no_f32 and a.arch == "sd-turbo":
             # north_star's 1e-3 bound is met by the exact-f32 MFMA mode (v_mfma_f32_16x16x4_f32 = an fmaf chain): its throughput and
             # its parity ride in the same line, a few replays of the same batch (roofline against the 157.3 TFLOP/s f32 peak)
@@ -470,9 +621,46 @@ def main():
                 rec["e2e_mfma_frac_f32"] = round(B / dt32 * falg / 1e12 / PEAK_TF["f32"], 4)
             rec["f32_note"] = ("the same batch through the exact-f32 MFMA mode (fp32 activations and weights, 157.3 TFLOP/s peak): 3 hipGraph "
                                "replays after 2 warm-ups; parity_max_abs_f32 = its image 0 vs the CPU fp32 oracle")
+            if not a.no_latency and B != 1:
+                # the within-1e-3 answer to north_star's bs = 1 target (0.11 s per image on A100): p50 of one image in the exact-f32 mode
+                p32_1 = (m32.get_plan(1, a.size, a.size, direction=a.direction) if a.model == "cyclegan" else
+                         m32.get_plan(1, a.size, a.size, stochastic=a.stochastic, r=a.gamma))
+                m32.stage(p32_1, xd[:1], cap.to(dev), eps[:1].to(dev), noise[:1].to(dev) if a.stochastic else None)
+                for _ in range(2):
+                    p32_1.replay()
+                torch.cuda.synchronize()
+                lat = []
+                for _ in range(7):
+                    t = time.perf_counter()
+                    p32_1.replay()
+                    torch.cuda.synchronize()
+                    lat.append((time.perf_counter() - t) * 1e3)
+                rec["latency_bs1_ms_p50_f32"] = round(statistics.median(lat), 3)
             m32.release_plans()
             del m32, p32
             torch.cuda.empty_cache()
+        if a.dtype == "bf16" and not a.no_modes and a.arch == "sd-turbo":
+            # the 16-bit precision modes side by side on the SAME batch: throughput + parity of image 0 (filled in below)
+            rec["precision_modes"] = {"bf16": {"images_per_s": round(value, 2)}}
+            for mname, kw in (("mixed_unet_f16_vae_bf16", dict(dtype=torch.bfloat16, unet_dtype=torch.float16)), ("f16", dict(dtype=torch.float16))):
+                mm = type(model)(weights=weights, device=dev, **kw)
+                pm = (mm.get_plan(B, a.size, a.size, direction=a.direction) if a.model == "cyclegan" else
+                      mm.get_plan(B, a.size, a.size, stochastic=a.stochastic, r=a.gamma))
+                mm.stage(pm, xd, cap.to(dev), eps.to(dev), noise.to(dev) if a.stochastic else None)
+                for _ in range(3):
+                    pm.replay()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(8):
+                    pm.replay()
+                torch.cuda.synchronize()
+                rec["precision_modes"][mname] = {"images_per_s": round(8 * B / (time.perf_counter() - t), 2)}
+                mode_out[mname] = pm.out[:1].float().cpu()
+                mm.release_plans()
+                del mm, pm
+                torch.cuda.empty_cache()
+            if "images_per_s_f32" in rec:
+                rec["precision_modes"]["f32_exact"] = {"images_per_s": rec["images_per_s_f32"]}
         if not a.no_cpu_baseline:
             cb, ref = cpu_baseline(a, weights, x, cap, eps, noise)
             rec["cpu_baseline"] = cb
@@ -484,6 +672,17 @@ def main():
             rec["parity_note"] = "GPU %s image 0 of the benchmarked batch vs the CPU fp32 oracle on the same inputs, outputs in [-1,1]" % a.dtype
             if out32 is not None:
                 rec["parity_max_abs_f32"] = round(float((out32 - ref).abs().max()), 7)
+            if "precision_modes" in rec:
+                pm_ = rec["precision_modes"]
+                pm_["bf16"].update(parity_max_abs=rec["parity_max_abs"], parity_psnr_db=rec["parity_psnr_db"])
+                for mname, o in mode_out.items():
+                    dd = (o - ref).abs()
+                    pm_[mname].update(parity_max_abs=round(float(dd.max()), 5),
+                                      parity_psnr_db=round(10 * torch.log10(torch.tensor(4.0 / max(float((dd ** 2).mean()), 1e-20))).item(), 2))
+                if out32 is not None and "f32_exact" in pm_:
+                    pm_["f32_exact"].update(parity_max_abs=rec["parity_max_abs_f32"])
+                pm_["note"] = ("image 0 of the benchmarked batch vs the CPU fp32 oracle; mixed = UNet in fp16 (the network whose error the 1-step scheduler "
+                               "multiplies by 14.6) with the VAE in bf16 (whose real activations overflow fp16)")
     print(json.dumps(rec), flush=True)
 
 

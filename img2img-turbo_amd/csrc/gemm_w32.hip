@@ -62,6 +62,14 @@ __device__ __forceinline__ void sopaque(unsigned&) {}
 __device__ __forceinline__ void sopaque(unsigned& x) { asm volatile("" : "+v"(x)); }
 #endif
 
+// wave-level ordering point between LDS writes and reads of OTHER lanes of the same wave (the hardware's LDS queue is in order per wave:
+// no instruction; the emulator's lanes are fibers and need the rendezvous)
+#ifdef I2I_EMU
+__device__ __forceinline__ void g32_wave_sync() { int z = 0; (void)__shfl_xor(z, 1); }
+#else
+__device__ __forceinline__ void g32_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#endif
+
 __device__ __attribute__((aligned(16))) uint32_t g32_zero16[4] = {0u, 0u, 0u, 0u};   // DMA source of the dummy pieces
 
 // c + a.x*b.x + a.y*b.y in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16): two stored channels per instruction for the statistics
@@ -85,9 +93,16 @@ constexpr int G32_NW = 4, G32_BK = 64, G32_KQ = 4;       // waves per workgroup 
 // SPLITK: grid y = p.splitk slices of the K stages; every slice writes its raw fp32 accumulators to p.ws [slice][M][N] and
 // splitk_reduce (gemm_dma.hip) sums them in a fixed order and applies the epilogue -- the 3x3 convolutions of the UNet's 8 x 8 /
 // 16 x 16 planes at batch 8 (M = 512 .. 2048 rows against K = 11520 .. 23040: 16 - 32 tiles would leave the chip empty).
-template <typename T, int FMW, int FNW, int RING, bool GEGLU, bool GATHER = false, bool STATS = false, bool SPLITK = false>
+// LNF: LayerNorm folded into the GEMM (i2i_igemm_params.ln_cs): the A rows are the UN-normalised tokens, the weights carry the LayerNorm
+// weight (W' = W * gamma, folded by the device-side merge), and the epilogue computes rstd * (acc - mu * colsum[n]) + bias'[n].  mu / rstd of
+// a row come from the row fragments the MFMAs consume anyway: 8 v_dot2c per fragment and k16 step (sum and sum of squares of the lane's 8
+// elements), in the MFMA shadow.  With n_trans the column tiles at and beyond it issue their MFMAs with the operands in the OTHER order
+// (A-operand = token rows): an accumulator lane then owns 8 consecutive TOKENS of one output column after the half exchange and stores
+// them as 16 bytes of the transposed output c2 -- the self-attention V^T [C][B*T] -- so to_q | to_k | to_v is one launch.
+template <typename T, int FMW, int FNW, int RING, bool GEGLU, bool GATHER = false, bool STATS = false, bool SPLITK = false, bool LNF = false>
 __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igemm_params p) {
     static_assert(!(GEGLU && (GATHER || STATS)) && !(SPLITK && (GEGLU || STATS)), "");
+    static_assert(!(LNF && (GATHER || STATS || SPLITK)), "");
     constexpr int NW = G32_NW, BK = G32_BK, KQ = G32_KQ;
     constexpr int WTM = 32 * FMW, BM = NW * WTM, BN = 32 * FNW;
     constexpr int STAGE = (BM + BN) * 128;
@@ -117,6 +132,11 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const bool m_fast = p.N > p.M;
     const int m0 = (m_fast ? bid % ntm : bid / ntn) * BM, n0 = (m_fast ? bid / ntm : bid % ntn) * BN;
+    // LNF with a transposed column range: the tiles at and beyond n_trans run a second copy of the WHOLE body with the MFMA operands in the
+    // other order (uniform over the workgroup; two straight-line bodies instead of one body with 160 accumulator phis at every join)
+    const bool trans = LNF && !GEGLU && p.n_trans > 0 && n0 >= p.n_trans;
+    auto body = [&](auto trc) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(trc)::value != 0;
     // K % 64 == 0 (host check).  SPLITK: this workgroup's stages are s0 .. s0 + nk - 1 (a slice past the end has nk = 0 and
     // writes zeros)
     int s0 = 0, nk = p.K / BK;
@@ -244,6 +264,14 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     const int rd_b = BM * 128 + l31 * 128 + ((lh ^ gswz3(l31)) << 4);
 
     chunk_t xf[2][FMW], wf[2][FNW];
+    // LNF: (sum, sum of squares) over the K elements this lane has seen of fragment row i (its k half: lanes l and l + 32 are combined
+    // after the loop); trans: this column tile belongs to the transposed range (uniform over the workgroup)
+    typedef T tx2 __attribute__((ext_vector_type(2)));
+    float ls[LNF ? FMW : 1], lq[LNF ? FMW : 1];
+#pragma unroll
+    for (int i = 0; i < (LNF ? FMW : 1); ++i) { ls[i] = 0.f; lq[i] = 0.f; }
+    tx2 ones2;
+    ones2[0] = (T)1.0f; ones2[1] = (T)1.0f;
 
     // The batch of stage s + RING (OPB pieces per wave) is issued in the window that opens after barrier P_s: PPS + PREM
     // pieces in the last k16 step of stage s (window slot 0), PPS in each of the k16 steps 0 .. KQ-2 of stage s + 1.
@@ -266,15 +294,31 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
 #pragma unroll
         for (int i = 0; i < FMW; ++i)
 #pragma unroll
-            for (int j = 0; j < FNW; ++j) acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
-        constexpr int TOT = NRD + pn;
+            for (int j = 0; j < FNW; ++j) {
+                if constexpr (TR) acc[i][j] = mma32(xf[cur][i], wf[cur][j], acc[i][j]);
+                else acc[i][j] = mma32(wf[cur][j], xf[cur][i], acc[i][j]);
+            }
+        if constexpr (LNF) {
+#pragma unroll
+            for (int i = 0; i < FMW; ++i)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    tx2 d;
+                    d[0] = xf[cur][i][2 * h]; d[1] = xf[cur][i][2 * h + 1];
+                    ls[i] = g32_dot2(d, ones2, ls[i]);
+                    lq[i] = g32_dot2(d, d, lq[i]);
+                }
+        }
+        constexpr int TOT = NRD + pn, NVAL = LNF ? 8 * FMW : 0;
         static_for_g<NMM>([&](auto mc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value;
             constexpr int lo = (TOT * m) / NMM, hi = (TOT * (m + 1)) / NMM;
             constexpr int nr = (hi < NRD ? hi : NRD) - (lo < NRD ? lo : NRD), nd = (hi - lo) - nr;
+            constexpr int nv = (NVAL * (m + 1)) / NMM - (NVAL * m) / NMM;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if constexpr (nr > 0) __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
             if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x010, nd, 0);
+            if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
         });
     };
 
@@ -309,28 +353,86 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     // stage s + RING; P_s also publishes stage s + 1 (each wave waits for its own pieces with a counted vmcnt just before).
     // VMEM issue order per wave: [W_0] [W_1] ... (OPB pieces each); at P_s the batch W_{s+RING-1} is complete and everything
     // up to W_{s+1} must have landed: exactly the RING-2 batches behind it may still fly.
-    int cur = 0;
-    for (int s = 0; s < nk; ++s) {
-        const int nxt = cur + 1 == RING ? 0 : cur + 1;
-        const int ca = rd_a + cur * STAGE, cb = rd_b + cur * STAGE;
-        kstep(icg<0>{}, ca, cb, icg<1>{}, icg<win_lo(1)>{}, icg<win_n(1)>{});
-        kstep(icg<1>{}, ca, cb, icg<2>{}, icg<win_lo(2)>{}, icg<win_n(2)>{});
-        kstep(icg<2>{}, ca, cb, icg<3>{}, icg<win_lo(3)>{}, icg<win_n(3)>{});
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(RING - 2) * OPB>();
-        lds_barrier();
-        {                                                  // the window of stage s + RING opens: slot `cur` is free now
-            const int pend = s + RING < nk ? s + RING : -1;
-            if (pend == s_sw && pend >= 0) a_voff_for(true);
-            open_window(pend, cur);
+    {
+        int cur = 0;
+        for (int s = 0; s < nk; ++s) {
+            const int nxt = cur + 1 == RING ? 0 : cur + 1;
+            const int ca = rd_a + cur * STAGE, cb = rd_b + cur * STAGE;
+            kstep(icg<0>{}, ca, cb, icg<1>{}, icg<win_lo(1)>{}, icg<win_n(1)>{});
+            kstep(icg<1>{}, ca, cb, icg<2>{}, icg<win_lo(2)>{}, icg<win_n(2)>{});
+            kstep(icg<2>{}, ca, cb, icg<3>{}, icg<win_lo(3)>{}, icg<win_n(3)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<(RING - 2) * OPB>();
+            lds_barrier();
+            {                                              // the window of stage s + RING opens: slot `cur` is free now
+                const int pend = s + RING < nk ? s + RING : -1;
+                if (pend == s_sw && pend >= 0) a_voff_for(true);
+                open_window(pend, cur);
+            }
+            const int na = rd_a + nxt * STAGE, nb = rd_b + nxt * STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(icg<3>{}, na, nb, icg<0>{}, icg<win_lo(0)>{}, icg<win_n(0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
-        const int na = rd_a + nxt * STAGE, nb = rd_b + nxt * STAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        kstep(icg<3>{}, na, nb, icg<0>{}, icg<win_lo(0)>{}, icg<win_n(0)>{});
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
     }
     wait_vmcnt<0>();                                       // (tail windows: dummy pieces still in flight)
+
+    // ---- LNF: mean / rstd of the rows this lane's fragments cover (row l31 of fragment i: the two k halves live in lanes l and l + 32)
+    float ra[LNF ? FMW : 1], rb[LNF ? FMW : 1];           // rstd, -rstd * mean
+    if constexpr (LNF) {
+        const float invk = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < FMW; ++i) {
+            float s0 = ls[i], s1 = ls[i], q0 = lq[i], q1 = lq[i];
+            half_swap(s0, s1);                             // lanes 0-31: (own, partner's); lanes 32-63: (partner's, own)
+            half_swap(q0, q1);
+            const float mu = (s0 + s1) * invk;
+            const float var = fmaxf((q0 + q1) * invk - mu * mu, 0.f);
+            ra[i] = rsqrtf(var + p.ln_eps);
+            rb[i] = -ra[i] * mu;
+        }
+        if constexpr (TR) {
+            // ---- the transposed range: acc[i][j][r] = token row m0 + wave*WTM + i*32 + 8*(r>>2) + 4*lh + (r&3), column n0 + j*32 + l31.
+            // Every lane needs (rstd, -rstd*mu) of the 8 token rows of a register-quad pair: the table goes through LDS behind the
+            // operand ring (wave-private rows; the LDS queue of a wave is in order).
+            float* st = (float*)(i2i_smem + RING * STAGE) + (wave * WTM) * 2;
+            if (lh == 0) {
+#pragma unroll
+                for (int i = 0; i < FMW; ++i) { st[(i * 32 + l31) * 2] = ra[i]; st[(i * 32 + l31) * 2 + 1] = rb[i]; }
+            }
+            g32_wave_sync();
+            T* __restrict__ out2 = (T*)p.c2;
+            typedef T tx8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int j = 0; j < FNW; ++j) {
+                const int n = n0 + j * 32 + l31;
+                const bool nok = n < p.N;
+                const float csn = p.ln_cs[nok ? n : 0], bn = p.bias[nok ? n : 0];
+#pragma unroll
+                for (int i = 0; i < FMW; ++i)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        f32x4 qa, qb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { qa[r] = acc[i][j][8 * pr + r]; qb[r] = acc[i][j][8 * pr + 4 + r]; }
+                        float v[8];
+                        widen_pair(qa, qb, v);             // the lane's 8 consecutive tokens 16*pr + 8*lh .. +7 of fragment i
+                        const int mr = i * 32 + 16 * pr + 8 * lh;
+                        const int m = m0 + wave * WTM + mr;
+                        const f32x4 t0 = *(const f32x4*)(st + mr * 2), t1 = *(const f32x4*)(st + mr * 2 + 4),
+                                    t2 = *(const f32x4*)(st + mr * 2 + 8), t3 = *(const f32x4*)(st + mr * 2 + 12);
+                        const float a8[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3[0], t3[2]};
+                        const float b8[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3[1], t3[3]};
+                        tx8 o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(__builtin_fmaf(a8[r], v[r], __builtin_fmaf(b8[r], csn, bn)));
+                        if (nok && m < p.M) *(tx8*)(out2 + (int64_t)(n - p.n_trans) * p.ldc2 + m) = o;      // M % 8 == 0 (host check)
+                    }
+            }
+            return;
+        }
+    }
 
     // ---- epilogue.  acc[i][j][r]: row m0 + wave*WTM + i*32 + l31, column n0 + j*32 + 8*(r>>2) + 4*lh + (r&3).  Register quads
     // (2*pr, 2*pr+1) are half-exchanged between lanes l and l+32 (widen_pair): the lane then owns the 8 consecutive columns
@@ -425,6 +527,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
         // branch-free: without a bias the loads read the first bytes of the weights and the values are selected away
         constexpr int NBQ = GEGLU ? 4 : 2;
         f32x4 bb[2][NBQ];
+        f32x4 cb[LNF ? 2 : 1][LNF ? NBQ : 1];              // LNF: the column sums of the folded weights, like the bias
         const bool has_bias = GEGLU ? p.bias != nullptr : p.bias_mode == 1;
         const float* const bsrc = has_bias ? p.bias : (const float*)p.b;
         auto bload = [&](auto tc) __attribute__((always_inline)) {
@@ -436,6 +539,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
                     const f32x4 b = *(const f32x4*)(bsrc + nb + (GEGLU ? 8 * q + 4 * lh : 4 * q));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bb[t & 1][q][r] = has_bias ? b[r] : 0.f;
+                    if constexpr (LNF) cb[t & 1][q] = *(const f32x4*)(p.ln_cs + (col_ok(tc) ? col_in(tc) : 0) + (GEGLU ? 8 * q + 4 * lh : 4 * q));
                 }
             }
         };
@@ -453,12 +557,10 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
                 }
             }
         };
-        typedef T tx2 __attribute__((ext_vector_type(2)));
         float gacc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) gacc[v] = 0.f;
-        tx2 ones;
-        ones[0] = (T)1.0f; ones[1] = (T)1.0f;
+        const tx2 ones = ones2;
         bload(icg<0>{});
         rload(icg<0>{});
         static_for_g<NBLK>([&](auto tc) __attribute__((always_inline)) {
@@ -477,8 +579,14 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float a = __builtin_fmaf(p.alpha, acc[i][t][4 * q + r], bb[t & 1][q][r]);
-                            const float g = __builtin_fmaf(p.alpha, acc[i][t][8 + 4 * q + r], bb[t & 1][2 + q][r]);
+                            float a, g;
+                            if constexpr (LNF) {           // rstd * acc - rstd * mu * colsum + bias'   (alpha = 1: host check)
+                                a = __builtin_fmaf(ra[i], acc[i][t][4 * q + r], __builtin_fmaf(rb[i], cb[t & 1][q][r], bb[t & 1][q][r]));
+                                g = __builtin_fmaf(ra[i], acc[i][t][8 + 4 * q + r], __builtin_fmaf(rb[i], cb[t & 1][2 + q][r], bb[t & 1][2 + q][r]));
+                            } else {
+                                a = __builtin_fmaf(p.alpha, acc[i][t][4 * q + r], bb[t & 1][q][r]);
+                                g = __builtin_fmaf(p.alpha, acc[i][t][8 + 4 * q + r], bb[t & 1][2 + q][r]);
+                            }
                             const float o = a * gelu_erf_f(g);
                             if (q == 0) qa[r] = o; else qb[r] = o;
                         }
@@ -492,8 +600,16 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
                 const int m = mrow + i * 32;
                 if (!FULL && (!nok || m >= p.M)) continue;
                 if constexpr (!GEGLU) {
+                    if constexpr (LNF) {                   // (lanes l and l + 32 hold the same row: ra / rb survive the exchange)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = __builtin_fmaf(p.alpha, v[r], bb[t & 1][0][r]); v[4 + r] = __builtin_fmaf(p.alpha, v[4 + r], bb[t & 1][1][r]); }
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = __builtin_fmaf(ra[i], v[r], __builtin_fmaf(rb[i], cb[t & 1][0][r], bb[t & 1][0][r]));
+                            v[4 + r] = __builtin_fmaf(ra[i], v[4 + r], __builtin_fmaf(rb[i], cb[t & 1][1][r], bb[t & 1][1][r]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = __builtin_fmaf(p.alpha, v[r], bb[t & 1][0][r]); v[4 + r] = __builtin_fmaf(p.alpha, v[4 + r], bb[t & 1][1][r]); }
+                    }
                 }
                 if constexpr (RES) {
 #pragma unroll
@@ -517,6 +633,7 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
         });
         if constexpr (STATS) stats_out(gacc);
     };
+    static_assert(G32_EPI_PIPE || !LNF, "the LayerNorm fold lives in the pipelined epilogue only");
     if (G32_EPI_PIPE) {
         const bool full = m0 + BM <= p.M && n0 + BN <= p.N;      // (uniform)
         if (full) { if (res) pipe(icg<1>{}, icg<1>{}); else pipe(icg<1>{}, icg<0>{}); }
@@ -525,12 +642,10 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
     }
     if constexpr (!GEGLU) {
         // STATS: (sum, sum of squares) of the lane's stored values per 4-channel quad: index ((j*2 + pr)*2 + h)*2 + {0, 1}
-        typedef T tx2 __attribute__((ext_vector_type(2)));
         float gacc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) gacc[v] = 0.f;
-        tx2 ones;
-        ones[0] = (T)1.0f; ones[1] = (T)1.0f;
+        const tx2 ones = ones2;
 #pragma unroll
         for (int j = 0; j < FNW; ++j) {
 #pragma unroll
@@ -638,6 +753,10 @@ __global__ __launch_bounds__(G32_NW * 64, 1) void gemm_w32_kernel(const i2i_igem
             }
         }
     }
+    };      // body
+    if constexpr (LNF && !GEGLU) {
+        if (trans) body(icg<1>{}); else body(icg<0>{});
+    } else body(icg<0>{});
 }
 
 // tile ids 50..59 (i2i_igemm_params.tile): 50 = auto among the configurations
@@ -678,9 +797,15 @@ template <typename T, int FMW, int FNW, int RING = 3>
 int launch_g32(const i2i_igemm_params& p, hipStream_t s) {
     constexpr int BM = G32_NW * 32 * FMW, BN = 32 * FNW;
     const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
-    const size_t smem = (size_t)RING * (BM + BN) * 128;
+    const size_t smem = (size_t)RING * (BM + BN) * 128 + (p.ln_cs && p.n_trans > 0 ? (size_t)BM * 8 : 0);      // (+ the row-statistics table of the transposed tiles)
     const dim3 g(tiles), b(G32_NW * 64);
     const bool gather = p.ks == 3, stats = p.gn_part != nullptr;
+    if (p.ln_cs) {
+        if (gather || stats || p.splitk > 1) return i2i::fail(I2I_ERR_BAD_ARG, "gemm_w32: the LayerNorm fold is a plain GEMM epilogue (no gather / split-K / statistics)");
+        if (p.geglu) hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, true, false, false, false, true>), g, b, smem, s, p);
+        else hipLaunchKernelGGL((gemm_w32_kernel<T, FMW, FNW, RING, false, false, false, false, true>), g, b, smem, s, p);
+        return i2i::check_launch("gemm_w32<ln>");
+    }
     // (the gather, split-K and the statistics epilogue exist for the 3-deep ring only, the statistics for 128-column tiles only:
     // gemm_w32_eligible / gemm_w32_gn_parts admit nothing else)
     if constexpr (RING == 3) {
@@ -751,6 +876,13 @@ bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype) {
     if (p.M < 1 || p.N < 32 || p.N % 8) return false;
     if (p.geglu && (p.N % 32 || p.bias_mode == 2)) return false;
     if (p.gn_part && g32_gn_parts(p, p.gn_part_groups) == 0) return false;
+    if (p.ln_cs) {      // LayerNorm fold: plain one-source GEMM, per-column bias' present, alpha 1, no slices / statistics
+        if (gather || p.c1 || p.a1 || p.splitk > 1 || p.gn_part || p.alpha != 1.0f || !p.bias || p.bias_mode != 1 || (((uintptr_t)p.ln_cs) & 15)) return false;
+        if (p.n_trans) {
+            const int bn = g32_geometry(g32_cfg(p)).bn;
+            if (p.geglu || p.res || p.n_trans < 0 || p.n_trans >= p.N || p.n_trans % bn || !p.c2 || (((uintptr_t)p.c2) & 15) || p.ldc2 % 8 || p.M % 8) return false;
+        }
+    } else if (p.n_trans || p.c2) return false;
     const uint64_t a_rows = gather ? (uint64_t)p.nimg * p.hin * p.win : (uint64_t)p.M;
     const uint64_t a_bytes = a_rows * (uint64_t)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 2u, b_bytes = (uint64_t)p.N * p.ldb * 2u;
     if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;

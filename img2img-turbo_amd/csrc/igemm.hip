@@ -327,6 +327,8 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
         return i2i::fail(I2I_ERR_BAD_ARG, "igemm: subpix weights need a 3x3 conv kernel (ups=1, 3x3 s1 p1, cin %% slab == 0, source plane >= 8x16, ldb = 4*cin)");
     if (p.k2_a && !(i2i::conv3x3_w32_eligible(p, dtype) && ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype)))))
         return i2i::fail(I2I_ERR_UNSUPPORTED, "igemm: the second contraction (k2_a) is implemented by the wide-tile conv only (query i2i_igemm_route)");
+    if ((p.ln_cs || p.n_trans || p.c2) && !routes_to_gemm_w32(p, dtype))
+        return i2i::fail(I2I_ERR_UNSUPPORTED, "igemm: the LayerNorm fold (ln_cs / n_trans) is implemented by the wide GEMM only (query i2i_igemm_route)");
     const bool w32_forced = p.tile >= 40 && p.tile <= 49;      // 32x32x16-MFMA wide-tile conv (conv3x3_w32.hip)
     if (w32_forced && !i2i::conv3x3_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (w32 conv) not applicable", p.tile);
     if (w32_forced || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32(p, dtype, s);

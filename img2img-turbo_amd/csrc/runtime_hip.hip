@@ -91,4 +91,8 @@ int rt_zero(void* dst, size_t bytes) {
     I2I_HIP(hipMemset(dst, 0, bytes));
     return I2I_OK;
 }
+int rt_sync() {
+    I2I_HIP(hipDeviceSynchronize());
+    return I2I_OK;
+}
 }  // namespace i2i

@@ -25,6 +25,54 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def shared_weights(build, rank, world, tag="weights"):
+    """One host copy of the generator weights for all ranks of a node: rank 0 runs ``build()`` (a checkpoint read, or bench.py's
+    synthesis of ~950 M random parameters) and writes the state dicts to a safetensors file in /dev/shm; the other ranks map that
+    file (safetensors loads are mmap views: every rank's host tensors are the SAME pages) instead of building 8 identical copies
+    concurrently.  Weak-scaling set-up time then does not grow with the rank count.  The file is unlinked once every rank has
+    mapped it (the mappings keep the pages alive).  world == 1: just ``build()``."""
+    if world <= 1:
+        return build()
+    import json
+    from dataclasses import asdict
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    from .arch import UNetArch, VAEArch
+    from .weights import GeneratorWeights
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
+    path = os.path.join(base, "i2i_%s_%s_%s.safetensors" % (tag, os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+    if rank == 0:
+        w = build()
+        flat = {}
+        for pre, sd in (("unet/", w.unet), ("vae/", w.vae), ("vae_b2a/", w.vae_b2a or {})):
+            for k, v in sd.items():
+                flat[pre + k] = v.contiguous()
+        meta = {"unet_arch": json.dumps(asdict(w.unet_arch)), "vae_arch": json.dumps(asdict(w.vae_arch)),
+                "unet_scaling": json.dumps(w.unet_scaling), "vae_scaling": json.dumps(w.vae_scaling),
+                "meta": json.dumps(w.meta, default=str), "has_b2a": "1" if w.vae_b2a is not None else "0"}
+        save_file(flat, path + ".tmp", metadata=meta)
+        os.replace(path + ".tmp", path)
+    barrier()
+    if rank != 0:
+        unet, vae, b2a = {}, {}, {}
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata()
+            for k in f.keys():
+                pre, _, name = k.partition("/")
+                {"unet": unet, "vae": vae, "vae_b2a": b2a}[pre][name] = f.get_tensor(k)
+        tup = lambda d: {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()}
+        w = GeneratorWeights(unet, vae, UNetArch(**tup(json.loads(meta["unet_arch"]))), VAEArch(**tup(json.loads(meta["vae_arch"]))),
+                             json.loads(meta["unet_scaling"]), json.loads(meta["vae_scaling"]), b2a if meta["has_b2a"] == "1" else None,
+                             json.loads(meta["meta"]))
+    barrier()
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return w
+
+
 def shard_bounds(total, rank, world):
     """Contiguous, balanced slice [lo, hi) of ``total`` images for ``rank`` (first ``total % world`` ranks get one more)."""
     base, rem = divmod(total, world)

@@ -108,16 +108,18 @@ class Packer:
         self.nbytes += t.numel() * t.element_size()
         return t
 
-    def _pack_rows(self, w0, A=None, B=None, use_gamma=False, dst=None, row0=0):
+    def _pack_rows(self, w0, A=None, B=None, use_gamma=False, dst=None, row0=0, ln=None):
         """Packed [N][K] fp32 host rows (+ optional LoRA factors A [R][K], B [N][R]) -> rows ``row0..`` of the device tensor
-        the kernels read.  Adapted (or gamma-scaled) rows keep their fp32 master on the device and are (re)merged there."""
+        the kernels read.  Adapted (or gamma-scaled) rows keep their fp32 master on the device and are (re)merged there.
+        ``ln`` = dict(gamma, beta [K] device fp32, bias0 = host fp32 [N] or None, cs, bias_out = device fp32 vectors of the whole
+        tensor): fold the LayerNorm in front of the layer into these rows (i2i_lora_merge_params.kscale ..), always on the device."""
         from . import _capi
         n, k = w0.shape
         if dst is None:
             dst = torch.empty(n, k, dtype=self.dtype, device=self.device)
             self.nbytes += dst.numel() * dst.element_size()
         view = dst[row0:row0 + n]
-        if A is None and not use_gamma:
+        if A is None and not use_gamma and ln is None:
             view.copy_(w0.to(self.dtype))
             return dst
         assert k % 4 == 0
@@ -126,6 +128,11 @@ class Packer:
         keep = [dst, w0d, self.rg]
         p.dst, p.w0, p.N, p.K = view.data_ptr(), w0d.data_ptr(), n, k
         p.rank, p.use_gamma, p.rg = 0, int(use_gamma), self.rg.data_ptr()
+        if ln is not None:
+            b0 = None if ln.get("bias0") is None else self._up(ln["bias0"], torch.float32)
+            p.kscale, p.kshift, p.bias0 = ln["gamma"].data_ptr(), ln["beta"].data_ptr(), (0 if b0 is None else b0.data_ptr())
+            p.colsum, p.bias_out = ln["cs"][row0:].data_ptr(), ln["bias_out"][row0:].data_ptr()
+            keep += [ln["gamma"], ln["beta"], ln["cs"], ln["bias_out"], b0]
         if A is not None:
             Ad, Bd = self._up(A.reshape(A.shape[0], -1), torch.float32), self._up(B, torch.float32)
             assert Ad.shape == (A.shape[0], k) and Bd.shape == (n, A.shape[0]), (Ad.shape, Bd.shape, n, k)
@@ -256,6 +263,36 @@ class Packer:
             bs = [p[0][1] for p in parts]
             b = None if bs[0] is None else torch.cat(bs, 0)
             self.cache[key] = dict(w=dst, b=None if b is None else self._up(b, torch.float32), n=rows, ks=1)
+        return self.cache[key]
+
+    def ln_linear(self, names, norm_name, geglu=False):
+        """Linear layer(s) with the LayerNorm in front of them folded in (diffusers BasicTransformerBlock: norm1 -> attn1.to_q / to_k /
+        to_v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj): rows of ``names`` stacked (GEGLU rows interleaved per 16 as geglu_linear),
+        W' = W * gamma[k] written by the device-side merge together with the two per-row vectors the consumer GEMM needs
+        (i2i_igemm_params.ln_cs): -> dict(w, b = bias' = bias + W.beta, cs = row sums of the stored W', n, ks=1)."""
+        key = ("ln", norm_name, bool(geglu)) + tuple(names)
+        if key not in self.cache:
+            gamma, beta = self.norm(norm_name)
+            parts = [(self.base(n), self.lora(n)) for n in names]
+            rows = sum(p[0][0].shape[0] for p in parts)
+            k = parts[0][0][0].shape[1]
+            assert gamma.numel() == k, (norm_name, gamma.shape, k)
+            dst = torch.empty(rows, k, dtype=self.dtype, device=self.device)
+            cs = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            bout = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            self.nbytes += dst.numel() * dst.element_size() + 8 * rows
+            r0 = 0
+            for (w, b), ab in parts:
+                A, B = (ab if ab else (None, None))
+                if geglu:
+                    half = w.shape[0] // 2
+                    assert half % 16 == 0
+                    idx = torch.arange(half).reshape(-1, 16)
+                    idx = torch.cat([idx, idx + half], 1).reshape(-1)
+                    w, b, B = w[idx], (None if b is None else b[idx]), (None if B is None else B[idx])
+                self._pack_rows(w, A, B, dst=dst, row0=r0, ln=dict(gamma=gamma, beta=beta, bias0=b, cs=cs, bias_out=bout))
+                r0 += w.shape[0]
+            self.cache[key] = dict(w=dst, b=bout, cs=cs, n=rows, ks=1)
         return self.cache[key]
 
     def geglu_linear(self, name):

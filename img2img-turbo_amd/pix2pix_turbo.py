@@ -65,8 +65,12 @@ class TurboGeneratorBase(torch.nn.Module):
     MAX_PLANS = 8          # distinct (batch, size, mode) programs kept alive; each owns an activation pool + a hipGraph
 
     def __init__(self, weights: GeneratorWeights, device="cuda", dtype=torch.float32, lib=None,
-                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None):
+                 tokenizer=None, text_encoder=None, use_graph=True, fuse_gn=True, flash=True, plan_options=None, unet_dtype=None):
+        """``dtype``: element type of activations and packed weights (fp32 = the exact-MFMA parity mode).  ``unet_dtype``: another 16-bit
+        type for the UNet alone -- ``dtype=torch.bfloat16, unet_dtype=torch.float16`` keeps the VAE (whose real activations overflow fp16)
+        in bf16 and gives the UNet, whose error the 1-step scheduler multiplies by 14.6, fp16's three extra mantissa bits."""
         super().__init__()
+        self.unet_dtype_ = unet_dtype
         self.weights = weights
         self.device_ = torch.device(device)
         if self.device_.type == "cuda" and self.device_.index is None:
@@ -104,8 +108,8 @@ class TurboGeneratorBase(torch.nn.Module):
         return self.to_dtype(torch.float32)
 
     def to_dtype(self, dtype):
-        if dtype != self.dtype_:
-            self.dtype_ = dtype
+        if dtype != self.dtype_ or self.unet_dtype_ is not None:
+            self.dtype_, self.unet_dtype_ = dtype, None
             self.release_plans()
             self._packers.clear()
         return self
@@ -123,12 +127,13 @@ class TurboGeneratorBase(torch.nn.Module):
     def _packer(self, which):
         """One packer per network ('unet', 'vae', 'vae_b2a') and dtype: base weights are packed and uploaded once, the LoRA
         merge at the current r runs on the device (Packer.set_scale)."""
-        key = (self.dtype_, which)
+        dt = (self.unet_dtype_ or self.dtype_) if which == "unet" else self.dtype_
+        key = (dt, which)
         if key not in self._packers:
             w = self.weights
             sd, sc = {"unet": (w.unet, w.unet_scaling), "vae": (w.vae, w.vae_scaling), "vae_b2a": (w.vae_b2a, w.vae_scaling)}[which]
             with self._on_device():
-                self._packers[key] = Packer(sd, sc, self.dtype_, self.device_, self.lib, self._r, self._r)
+                self._packers[key] = Packer(sd, sc, dt, self.device_, self.lib, self._r, self._r)
         return self._packers[key]
 
     def _get_packers(self, direction):
@@ -155,7 +160,7 @@ class TurboGeneratorBase(torch.nn.Module):
         (it is a dictionary lookup) before running with another r."""
         r_plan = float(r) if stochastic else 1.0
         self.set_lora_scale(r_plan)
-        key = (B, H, W, self.dtype_, stochastic, direction, ctx_batch, u8_io)
+        key = (B, H, W, self.dtype_, self.unet_dtype_, stochastic, direction, ctx_batch, u8_io)
         if key in self._plans:
             self._plans.move_to_end(key)
         else:
@@ -165,7 +170,7 @@ class TurboGeneratorBase(torch.nn.Module):
             with self._on_device():
                 self._plans[key] = ForwardPlan(self.lib, self.weights, B, H, W, self.dtype_, self.device_, stochastic=stochastic,
                                                r=self._r, direction=direction, ctx_batch=ctx_batch, fuse_gn=self.fuse_gn,
-                                               flash=self.flash, packers=self._get_packers(direction), **opts)
+                                               flash=self.flash, packers=self._get_packers(direction), unet_dtype=self.unet_dtype_, **opts)
             while len(self._plans) > self.MAX_PLANS:      # LRU: the evicted plan's graph and activation pool are released
                 _, old = self._plans.popitem(last=False)
                 old.release()

@@ -74,13 +74,20 @@ class ForwardPlan:
     of the plan: it lives in the packers' device scalars (Packer.set_scale), so one plan (and its hipGraph) serves every r."""
 
     def __init__(self, lib, weights, B, H, W, dtype, device, *, stochastic=False, r=1.0, direction="a2b",
-                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True):
+                 ctx_batch=1, fuse_gn=True, flash=True, out_dtype=None, packers=None, debug=False, dma_small=True, fuse_gn_stats=True, subpix=True, halo_min_tiles=160, u8_io=None, fuse_vae_attention=True,
+                 unet_dtype=None):
         assert H % 8 == 0 and W % 8 == 0, "input must be a multiple of 8 (src/inference_paired.py:38-41)"
         # H, W multiples of 8 suffice (src/inference_paired.py:38-41): latent sizes that are not multiples of 8 make the
         # UNet levels odd (70 -> 35 -> 18 -> 9), handled like diffusers' forward_upsample_size path (explicit sizes).
         self.lib, self.w8s, self.B, self.H, self.W = lib, weights, B, H, W
         self.dtype, self.device = dtype, device
         self.dt = O.DT[dtype]
+        # Per-network precision: `dtype` is the VAE's (activations, packed weights), `unet_dtype` the UNet's (default: the same).  The two
+        # meet in fp32 (posterior moments / latents in, eps-prediction out), so e.g. a bf16 VAE (whose real activations overflow fp16)
+        # can run beside an fp16 UNet (3 more mantissa bits where the 1-step scheduler multiplies the error by 14.6).
+        self.vae_dtype, self.unet_dtype = dtype, (unet_dtype or dtype)
+        assert (self.unet_dtype == torch.float32) == (dtype == torch.float32), "the exact-f32 mode covers both networks"
+
         self.stochastic, self.r = stochastic, (r if stochastic else 1.0)
         self.fuse_gn, self.flash = fuse_gn, flash
         self.fuse_gn_stats = fuse_gn_stats and not debug   # conv epilogues emit the next GroupNorm's partial sums
@@ -91,7 +98,7 @@ class ForwardPlan:
         self.ua, self.va = weights.unet_arch, weights.vae_arch
         vae_sd = weights.vae if (direction == "a2b" or weights.vae_b2a is None) else weights.vae_b2a
         if packers is None:
-            packers = (Packer(weights.unet, weights.unet_scaling, dtype, device, lib, self.r, self.r),
+            packers = (Packer(weights.unet, weights.unet_scaling, self.unet_dtype, device, lib, self.r, self.r),
                        Packer(vae_sd, weights.vae_scaling, dtype, device, lib, self.r, self.r))
         self.pu, self.pv = packers
         self.pool = Pool(device)
@@ -125,6 +132,13 @@ class ForwardPlan:
         self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
+        # round 6: LayerNorm folded into the GEMM behind it (norm1 -> to_q | to_k | to_v^T in ONE launch, norm2 -> to_q, norm3 -> GEGLU on the
+        # small planes: csrc/gemm_w32.hip LNF; 16-bit types) and GroupNorm statistics + apply as one two-launch op for the consumers that
+        # read a materialised operand (csrc/norm.hip gn_norm_kernel).  A/B hooks.
+        self.ln_fold = os.environ.get("I2I_LN_FOLD", "1") != "0" and self.unet_dtype != torch.float32
+        self.ln_fold_geglu_max_rows = int(os.environ.get("I2I_LN_FOLD_GEGLU_ROWS", "1024"))
+        self.gn_norm_fused = os.environ.get("I2I_GN_NORM", "1") != "0"
+        self._gnn_part_elems = 0
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -137,7 +151,7 @@ class ForwardPlan:
                      torch.zeros(B, 3, H, W, dtype=torch.float32, device=device))
         self.eps = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device)
         self.noise = torch.zeros(B, lat, h8, w8, dtype=torch.float32, device=device) if stochastic else None
-        self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=dtype, device=device)
+        self.ctx = torch.zeros(ctx_batch, 77, self.ua.cross_attention_dim, dtype=self.unet_dtype, device=device)
         self.out = (torch.zeros(B, H, W, 3, dtype=torch.uint8, device=device) if u8_io else
                     torch.zeros(B, 3, H, W, dtype=self.out_dtype, device=device))
         self._build()
@@ -146,6 +160,20 @@ class ForwardPlan:
         self.graph = None
 
     # ------------------------------------------------------------------ helpers
+    def _as(self, dtype):
+        """Context: record the ops inside with ``dtype`` as the element type (the UNet section of a mixed-precision plan)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = (self.dtype, self.dt)
+            self.dtype, self.dt = dtype, O.DT[dtype]
+            try:
+                yield
+            finally:
+                self.dtype, self.dt = old
+        return cm()
+
     def _add(self, op, label, flops=0, kernel=None, flops_exec=None, nbytes=0):
         """Record one launch.  ``kernel``: which HIP kernel the C dispatcher will pick for an igemm op (i2i_igemm_route),
         used only for reporting (bench.py groups timings by kernel).  ``flops``: algorithmic FLOPs of the reference op(s)
@@ -155,7 +183,7 @@ class ForwardPlan:
         self.op_flops_exec.append(flops if flops_exec is None else flops_exec)
         self.op_bytes.append(nbytes)       # algorithmic HBM bytes of the HBM-bound launches (norms, layout / latent ops); 0 = not priced
         self.op_kernel.append(kernel or {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax",
-                                        K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply",
+                                        K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply", K.OP_GN_NORM: "gn_norm",
                                         K.OP_IGEMM: "igemm_dma_kernel"}.get(op[0], "boundary/elementwise"))
 
     def _reroute(self, params, kernel):
@@ -187,7 +215,12 @@ class ForwardPlan:
         # leaves them zero); I2I_GN_SLICED=0 keeps one workgroup per (image, group set) (A/B hook)
         self.gn_counters = torch.zeros(max(self._gn_cnt_elems, 1), dtype=torch.int32, device=self.device)
         sliced = os.environ.get("I2I_GN_SLICED", "1") != "0"
+        # gn_norm (slice statistics + finalize-and-apply): per-slice partial sums.  One slab per plan: the program runs in order on one stream.
+        self.gnn_partial = torch.zeros(max(self._gnn_part_elems, 1), dtype=torch.float32, device=self.device)
         for p, which in self._pending_gn:   # patch pointers now that the scratch exists
+            if which == "norm":
+                p.partial = self.gnn_partial.data_ptr()
+                continue
             if which == "stats":
                 p.partial, p.ss = self.gn_partial.data_ptr(), self.gn_ss.data_ptr()
                 p.counters = self.gn_counters.data_ptr() if sliced else 0
@@ -308,6 +341,10 @@ class ForwardPlan:
         ``k2`` = dict(x=Act at output resolution, w=packed 1x1 weights, label, [bias], [fallback]): a second contraction folded
         into this launch when the kernel it routes to takes one (i2i_igemm_params.k2_a); the returned Act then has ``k2_fused``
         set; otherwise ``fallback()`` (if given) records the separate launch and its output becomes this launch's residual."""
+        # gn: False, or (packer, norm name, groups, eps) of the GroupNorm in front of this conv: the statistics launch is recorded HERE,
+        # once the route is known -- gn_stats for the kernels that apply the norm while staging their operand, the one-launch gn_norm
+        # (statistics + apply) for those that read a materialised operand
+        gn_spec, gn = (gn, True) if isinstance(gn, tuple) else (None, bool(gn))
         ks = ks or pw["ks"]
         pad = (ks // 2 if not asym else 0) if pad is None else pad
         hin, win = x.h, x.w
@@ -365,17 +402,29 @@ class ForwardPlan:
             if not ok_:
                 halo, force_tile, grp = True, 0, 0
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
+        one_launch_norm = gn and not fused and gn_spec is not None and self.gn_norm_fused and (x.c + c1) <= 4096
+        if gn_spec is not None and not one_launch_norm:
+            self.gn_stats(gn_spec[0], gn_spec[1], x, gn_spec[2], gn_spec[3], x1)
         if gn and not fused:
-            # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm that takes the small
-            # UNet planes / 1x1 projections has no operand prologue, and the extra pass is over a few MB at most
+            # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm / wide GEMM that take the UNet's
+            # planes / 1x1 projections have no operand prologue, and the extra pass is over a few MB at most
             ct = x.c + c1
             y = self.new(x.n, x.h, x.w, ct)
-            for src, coff in ((x, 0), (x1, x.c)):
-                if src is None:
-                    continue
-                op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
-                self._pending_gn.append((op[1], "apply"))
-                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
+            if one_launch_norm:
+                gamma, beta = gn_spec[0].norm(gn_spec[1])
+                S = int(self.lib.lib.i2i_gn_norm_slices(x.n, x.hw, ct))
+                self._gnn_part_elems = max(self._gnn_part_elems, x.n * S * gn_spec[2] * 2)
+                op = O.gn_norm(x.t, y.t, gamma, beta, None, nimg=x.n, hw=x.hw, groups=gn_spec[2], eps=gn_spec[3], act=act, nslices=S,
+                               x1=x1.t if x1 else None, c0=x.c, c1=c1, ld0=x.c, ld1=c1, ldy=ct)
+                self._pending_gn.append((op[1], "norm"))
+                self._add(op, label + ".gn_norm", nbytes=2 * x.n * x.hw * ct * self.esz)
+            else:
+                for src, coff in ((x, 0), (x1, x.c)):
+                    if src is None:
+                        continue
+                    op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+                    self._pending_gn.append((op[1], "apply"))
+                    self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
         mk = lambda tile_, splitk_, ws_: O.conv(
@@ -468,12 +517,36 @@ class ForwardPlan:
         self.flops += 2 * rows * pw["n"] * cin
         return out
 
+    def ln_gemm(self, pw, x2d, rows, cin, *, out=None, out_cols=None, geglu=0, label="", n_trans=0, out2=None, ldc2=0):
+        """LayerNorm + linear in one wide-GEMM launch (csrc/gemm_w32.hip LNF): ``x2d`` holds the UN-normalised rows, ``pw`` comes from
+        Packer.ln_linear (LayerNorm weight folded into W, colsum / bias' beside it).  With ``n_trans`` the output columns from there on
+        are written transposed to ``out2`` (row pitch ``ldc2``: the self-attention V^T).  Returns the output tensor, or None -- with
+        nothing recorded -- when the dispatcher would not run this op on the wide GEMM (the caller then keeps the LayerNorm launch)."""
+        n_out = pw["n"] // 2 if geglu else pw["n"]
+        cols = out_cols or (n_trans if n_trans else n_out)
+        own = out is None
+        if own:
+            out = self.pool.get(rows * cols, self.dtype)
+        op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"], ldc=cols,
+                    geglu=geglu, tile=50)
+        q = op[1]
+        q.ln_cs, q.ln_eps = pw["cs"].data_ptr(), 1e-5
+        if n_trans:
+            q.n_trans, q.c2, q.ldc2 = n_trans, out2.data_ptr(), ldc2
+        q._keep = tuple(q._keep) + (pw["cs"],) + ((out2,) if out2 is not None else ())
+        if self.lib.igemm_route(q, self.dt) != "gemm_w32_kernel":
+            if own:
+                self.pool.put(out)
+            return None
+        self._add(op, label, 2 * rows * pw["n"] * cin, kernel="gemm_w32_kernel")
+        self.flops += 2 * rows * pw["n"] * cin
+        return out
+
     # ------------------------------------------------------------------ blocks
     def resnet(self, pk, prefix, x: Act, cout, groups, eps, x1: Optional[Act] = None, arch=None) -> Act:
         split = x.c if x1 else None
-        self.gn_stats(pk, prefix + ".norm1", x, groups, eps, x1)
-        h = self.conv(pk.resnet_conv1(prefix, arch, split), x, x1=x1, gn=True, act=1, label=prefix + ".conv1")
-        self.gn_stats(pk, prefix + ".norm2", h, groups, eps)
+        n1, n2 = (pk, prefix + ".norm1", groups, eps), (pk, prefix + ".norm2", groups, eps)
+        h = self.conv(pk.resnet_conv1(prefix, arch, split), x, x1=x1, gn=n1, act=1, label=prefix + ".conv1")
         if pk.has(prefix + ".conv_shortcut"):
             # output = conv_shortcut(input) + conv2(...) (diffusers ResnetBlock2D): the 1x1 shortcut rides as a second contraction
             # of the conv2 launch when the wide-tile conv takes it (no launch of its own, no write + re-read of its output);
@@ -482,16 +555,16 @@ class ForwardPlan:
             if self.fuse_shortcut and x1 is None and x.c % 64 == 0:
                 k2 = dict(x=x, w=pk.conv(prefix + ".conv_shortcut"), label=prefix + ".conv_shortcut",
                           bias=pk.bias_sum(prefix + ".conv2", prefix + ".conv_shortcut"), fallback=sc_conv)
-                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, label=prefix + ".conv2", k2=k2)
+                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=n2, act=1, label=prefix + ".conv2", k2=k2)
                 if getattr(out, "k2_residual", None) is not None:
                     self.free(out.k2_residual)
             else:
                 sc = sc_conv()
-                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=sc, label=prefix + ".conv2")
+                out = self.conv(pk.conv(prefix + ".conv2"), h, gn=n2, act=1, res=sc, label=prefix + ".conv2")
                 self.free(sc)
         else:
             assert x1 is None
-            out = self.conv(pk.conv(prefix + ".conv2"), h, gn=True, act=1, res=x, label=prefix + ".conv2")
+            out = self.conv(pk.conv(prefix + ".conv2"), h, gn=n2, act=1, res=x, label=prefix + ".conv2")
         self.free(h)
         return out
 
@@ -583,18 +656,38 @@ class ForwardPlan:
             self._ckv = dict(k=kall, vt=vt, off=offs, tot=tot, ldvt=ldvt)      # never returned to the pool: read until the last block
         return self._ckv
 
-    def attention_block(self, pk, p, xn, x_res, B, T, C, heads, ctx=None, tk=None):
-        """attn1 (self) or attn2 (cross, ``ctx`` = text states).  Returns x_res + to_out(attn)."""
+    def attention_block(self, pk, p, xn, x_res, B, T, C, heads, ctx=None, tk=None, ln=None):
+        """attn1 (self) or attn2 (cross, ``ctx`` = text states).  Returns x_res + to_out(attn).
+        ``ln`` = name of the LayerNorm in front of the block: ``xn`` is then the UN-normalised tensor and the norm rides in the
+        projection launch (self-attention: to_q | to_k | to_v^T in one launch; cross-attention: to_q); returns None with nothing
+        recorded when that launch is not available (the caller runs the LayerNorm and calls again without ``ln``)."""
         d = C // heads
         scale = 1.0 / math.sqrt(d)
+        vt_fused = None
         if ctx is None:
             tk = T
-            qk = self.linear(pk.stacked_linear([p + ".to_q", p + ".to_k"]), xn, B * T, C, label=p + ".to_qk")
+            if ln is not None:
+                if not (self.flash and d == 64 and tk % 8 == 0 and pk.base(p + ".to_v")[1] is None):
+                    return None
+                nt = B * T
+                qk, vt_fused = self.pool.get(B * T * 2 * C, self.dtype), self.pool.get(C * nt, self.dtype)
+                if self.ln_gemm(pk.ln_linear([p + ".to_q", p + ".to_k", p + ".to_v"], ln), xn, B * T, C, out=qk, out_cols=2 * C,
+                                label=p + ".norm+to_qkv^T", n_trans=2 * C, out2=vt_fused, ldc2=nt) is None:
+                    self.pool.put(qk)
+                    self.pool.put(vt_fused)
+                    return None
+            else:
+                qk = self.linear(pk.stacked_linear([p + ".to_q", p + ".to_k"]), xn, B * T, C, label=p + ".to_qk")
             q, k, ldq, ldk, q_bs, k_bs = qk, qk[C:], 2 * C, 2 * C, T * 2 * C, T * 2 * C
             kv_src, kv_cin, kv_bs = xn, C, T * C
         else:
             cd = self.ua.cross_attention_dim
-            q = self.linear(pk.conv(p + ".to_q"), xn, B * T, C, label=p + ".to_q")
+            if ln is not None:
+                q = self.ln_gemm(pk.ln_linear([p + ".to_q"], ln), xn, B * T, C, label=p + ".norm+to_q")
+                if q is None:
+                    return None
+            else:
+                q = self.linear(pk.conv(p + ".to_q"), xn, B * T, C, label=p + ".to_q")
             ldq, q_bs = C, T * C
             qk = None
             merged = self.cross_kv_merged and p.endswith(".attn2")
@@ -610,7 +703,9 @@ class ForwardPlan:
         epc = 4 if self.dtype == torch.float32 else 8
         ldvt = (tk + epc - 1) // epc * epc
         vb = B if (ctx is None or self.ctx_batch > 1) else 1
-        if ctx is not None and merged:
+        if vt_fused is not None:
+            vt, ldvt, vt_stride = vt_fused, B * T, tk      # V^T_all [C][B*T] written by the projection launch: image b = column block b*T
+        elif ctx is not None and merged:
             vt, vt_stride = ck["vt"][ck["off"][p] * ldvt:], ck["tot"] * ldvt        # rows off .. off + C of every image's V^T_all
         else:
             wv = pk.conv(p + ".to_v")
@@ -671,8 +766,7 @@ class ForwardPlan:
         """Transformer2DModel (1 BasicTransformerBlock, linear projections): GN(eps 1e-6) -> proj_in -> [attn1, attn2, GEGLU FF] -> proj_out + x."""
         B, T, C = x.n, x.hw, x.c
         rows = B * T
-        self.gn_stats(pk, p + ".norm", x, groups, 1e-6)
-        h = self.conv(pk.conv(p + ".proj_in"), x, ks=1, gn=True, act=0, label=p + ".proj_in").t   # tokens [rows][C]
+        h = self.conv(pk.conv(p + ".proj_in"), x, ks=1, gn=(pk, p + ".norm", groups, 1e-6), act=0, label=p + ".proj_in").t   # tokens [rows][C]
         t = p + ".transformer_blocks.0"
 
         def ln(name, src):
@@ -681,17 +775,27 @@ class ForwardPlan:
             self._add(O.layernorm(src, y, g, b, rows=rows, c=C, eps=1e-5), name, nbytes=2 * rows * C * self.esz)
             return y
 
-        y = ln(t + ".norm1", h)
-        h2 = self.attention_block(pk, t + ".attn1", y, h, B, T, C, heads)
-        self.pool.put(y)
+        # LayerNorm folded into the projection behind it where the wide GEMM takes the launch (self.ln_fold), else its own launch
+        h2 = self.attention_block(pk, t + ".attn1", h, h, B, T, C, heads, ln=t + ".norm1") if self.ln_fold else None
+        if h2 is None:
+            y = ln(t + ".norm1", h)
+            h2 = self.attention_block(pk, t + ".attn1", y, h, B, T, C, heads)
+            self.pool.put(y)
         self.pool.put(h)
-        y = ln(t + ".norm2", h2)
-        h3 = self.attention_block(pk, t + ".attn2", y, h2, B, T, C, heads, ctx=self.ctx, tk=77)
-        self.pool.put(y)
+        h3 = self.attention_block(pk, t + ".attn2", h2, h2, B, T, C, heads, ctx=self.ctx, tk=77, ln=t + ".norm2") if self.ln_fold else None
+        if h3 is None:
+            y = ln(t + ".norm2", h2)
+            h3 = self.attention_block(pk, t + ".attn2", y, h2, B, T, C, heads, ctx=self.ctx, tk=77)
+            self.pool.put(y)
         self.pool.put(h2)
-        y = ln(t + ".norm3", h3)
-        ff = self.linear(pk.geglu_linear(t + ".ff.net.0.proj"), y, rows, C, geglu=1, label=t + ".ff.geglu")
-        self.pool.put(y)
+        # (norm3 -> GEGLU only where the launch is latency bound: at batch 8 the folded epilogue costs the GEGLU tiles their second
+        # workgroup per CU -- 197 + 80 registers -- and more than the LayerNorm launch it saves: profiles/r6b_*)
+        ff = (self.ln_gemm(pk.ln_linear([t + ".ff.net.0.proj"], t + ".norm3", geglu=True), h3, rows, C, geglu=1, label=t + ".norm3+ff.geglu")
+              if (self.ln_fold and rows <= self.ln_fold_geglu_max_rows) else None)
+        if ff is None:
+            y = ln(t + ".norm3", h3)
+            ff = self.linear(pk.geglu_linear(t + ".ff.net.0.proj"), y, rows, C, geglu=1, label=t + ".ff.geglu")
+            self.pool.put(y)
         h4 = self.linear(pk.conv(t + ".ff.net.2"), ff, rows, 4 * C, res=h3, label=t + ".ff.net.2")
         self.pool.put(ff)
         self.pool.put(h3)
@@ -727,8 +831,7 @@ class ForwardPlan:
         self.free(m)
         m3 = self.resnet(pk, "encoder.mid_block.resnets.1", m2, boc[-1], g, eps)
         self.free(m2)
-        self.gn_stats(pk, "encoder.conv_norm_out", m3, g, eps)
-        moments = self.conv(pk.encoder_out(), m3, gn=True, act=1, out_f32=1, label="encoder.conv_out+quant_conv")
+        moments = self.conv(pk.encoder_out(), m3, gn=(pk, "encoder.conv_norm_out", g, eps), act=1, out_f32=1, label="encoder.conv_out+quant_conv")
         self.free(m3)
         return moments, skips
 
@@ -776,8 +879,7 @@ class ForwardPlan:
                 self.free(h)
                 h = h2
         assert not res
-        self.gn_stats(pk, "conv_norm_out", h, g, eps)
-        e = self.conv(pk.conv("conv_out"), h, gn=True, act=1, out_f32=1, label="conv_out")     # eps-prediction kept fp32
+        e = self.conv(pk.conv("conv_out"), h, gn=(pk, "conv_norm_out", g, eps), act=1, out_f32=1, label="conv_out")     # eps-prediction kept fp32
         self.free(h)
         return e
 
@@ -812,8 +914,7 @@ class ForwardPlan:
                 skip_done = bool(getattr(h2, "k2_fused", False))
                 self.free(h)
                 h = h2
-        self.gn_stats(pk, "decoder.conv_norm_out", h, g, eps)
-        y = self.conv(pk.conv("decoder.conv_out"), h, gn=True, act=1, label="decoder.conv_out")
+        y = self.conv(pk.conv("decoder.conv_out"), h, gn=(pk, "decoder.conv_norm_out", g, eps), act=1, label="decoder.conv_out")
         self.free(h)
         return y
 
@@ -829,15 +930,16 @@ class ForwardPlan:
         moments, skips = self._vae_encoder(x)
         # x (= conv_in input) is not a skip; skips[0] is conv_in's output
         self.free(x)
-        u = self.new(B, h8, w8, 8)
         self.u32 = torch.zeros(B * h8 * w8 * lat, dtype=torch.float32, device=self.device)
         sf = self.va.scaling_factor
-        self._add(O.posterior(moments.t, self.eps, u.t, n=B, hw=h8 * w8, lat=lat, ldm=moments.c, ldu=8, sf=sf, r=self.r,
-                              r_dev=self.pv.rg if self.stochastic else None,
-                              noise=self.noise, noise_n=B, u_f32=self.u32, moments_f32=1), "posterior_sample")
-        self.free(moments)
-        e = self._unet(u)
-        self.free(u)
+        with self._as(self.unet_dtype):          # fp32 moments in, the UNet's element type out; eps-prediction comes back in fp32
+            u = self.new(B, h8, w8, 8)
+            self._add(O.posterior(moments.t, self.eps, u.t, n=B, hw=h8 * w8, lat=lat, ldm=moments.c, ldu=8, sf=sf, r=self.r,
+                                  r_dev=self.pv.rg if self.stochastic else None,
+                                  noise=self.noise, noise_n=B, u_f32=self.u32, moments_f32=1), "posterior_sample")
+            self.free(moments)
+            e = self._unet(u)
+            self.free(u)
         sa, s1 = one_step_scheduler_constants(self.ua.timestep)
         wpq, bpq = self.pv.small_f32("post_quant_conv")
         z = self.new(B, h8, w8, 8)

@@ -44,13 +44,18 @@ def _storage_key(t):
 
 def export_plan(plan, path, extra_tensors=()):
     """Write ``plan`` (a ForwardPlan) to ``path``.  Returns a small summary dict.  The plan must not be replaying while this runs
-    (the buffers' contents are read back through torch)."""
+    (the buffers' contents are read back through torch).
+
+    The packed weights are SHARED by every plan of a model and hold whatever LoRA / skip scale ``r`` was merged last (another plan's
+    ``r``, or 1.0 after a deterministic plan ran): ``plan._prepare()`` re-merges them at THIS plan's ``r`` before anything is read
+    back, and refuses a plan whose buffers were released (plan-cache eviction)."""
+    plan._prepare()
     named = {"x": plan.x_in, "ctx": plan.ctx, "eps": plan.eps, "out": plan.out}
     if getattr(plan, "noise", None) is not None:
         named["noise"] = plan.noise
     # (the GroupNorm scratch -- partial sums, (scale, shift) tables, ticket counters -- is patched into the ops after they were recorded:
     # plan._finish_gn_scratch; produced inside the program, zero at rest)
-    gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters")) if t is not None]
+    gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters", "gnn_partial")) if t is not None]
     return export_program(plan.prog, path, named, scratch=list(plan.pool.all) + gn_scratch, holders=[plan] + list(extra_tensors), device=plan.device)
 
 
@@ -164,7 +169,10 @@ def main(argv=None):
     ap.add_argument("--size", type=int, nargs="+", default=[512], help="H [W]")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--stochastic", action="store_true")
-    ap.add_argument("--gamma", type=float, default=1.0, help="LoRA / skip scale r the weights are merged at (stochastic plans)")
+    ap.add_argument("--gamma", type=float, default=None, help="LoRA / skip scale r the weights are merged at (stochastic plans; default 0.4, "
+                    "the reference's default: src/inference_paired.py:22)")
+    ap.add_argument("--sketch", action="store_true", help="with --u8: 'x' holds raw uint8 sketches, binarised in the boundary kernel as the sketch "
+                    "script does (F.to_tensor(img) < 0.5, src/inference_paired.py:56-58); implied by --stochastic --u8")
     ap.add_argument("--direction", default="a2b", choices=["a2b", "b2a"])
     ap.add_argument("--u8", action="store_true", help="uint8 NHWC boundary (to_tensor / Normalize / ToPILImage inside the boundary kernels)")
     ap.add_argument("--device", default="cuda:0")
@@ -196,11 +204,12 @@ def main(argv=None):
     else:
         from .pix2pix_turbo import Pix2Pix_Turbo
         model = Pix2Pix_Turbo(**kw)
-        u8 = (1.0, 0.0) if a.u8 else None
-        plan = model.get_plan(a.batch, H, W, stochastic=a.stochastic, r=a.gamma, u8_io=u8)
-    if plan.before_run is not None:
-        plan.before_run(plan)                       # merge the weights at this plan's r before they are saved
-    info = export_plan(plan, a.out)
+        # uint8 boundary: edge maps go through to_tensor (x / 255); the sketch model's input is the binarised sketch (threshold 128 =
+        # `F.to_tensor(img) < 0.5`), which is what Pix2Pix_Turbo.forward_u8(..., sketch=True) feeds -- a stochastic plan is the sketch model
+        u8 = ((1.0, 0.0, 128) if (a.sketch or a.stochastic) else (1.0, 0.0)) if a.u8 else None
+        gamma = a.gamma if a.gamma is not None else (0.4 if a.stochastic else 1.0)
+        plan = model.get_plan(a.batch, H, W, stochastic=a.stochastic, r=gamma, u8_io=u8)
+    info = export_plan(plan, a.out)                 # (re-merges the weights at this plan's r first: plan._prepare)
     print("wrote %s: %d ops, %d buffers, %.2f GB of weights, %.2f GB of scratch at load; boundary buffers %s"
           % (a.out, info["ops"], info["buffers"], info["data_bytes"] / 1e9, info["scratch_bytes"] / 1e9, info["io"]))
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 8
+#define I2I_ABI_VERSION 9
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -51,7 +51,9 @@ typedef enum {
     I2I_OP_GN_APPLY = 10,
     I2I_OP_EMBED = 11,
     I2I_OP_LORA_MERGE = 12,
-    I2I_OP_RESIZE_U8 = 13
+    I2I_OP_RESIZE_U8 = 13,
+    I2I_OP_GN_NORM = 14,
+    I2I_OP_NOP = 15            /* one empty kernel launch (bench.py's calibration: microseconds per hipGraph node) */
 } i2i_opcode;
 
 /* ---------------------------------------------------------------------------------------------
@@ -117,6 +119,18 @@ typedef struct {
      * "conv3x3_w32_kernel<SUBPIX>"), anything else returns I2I_ERR_UNSUPPORTED. */
     const void* k2_a; const void* k2_b;
     int32_t k2_c, k2_lda, k2_ldb;
+    /* LayerNorm folded into this GEMM (ABI v9; the wide GEMM only, ks = 1, one source, no split-K): `a0` holds the UN-normalised rows x and
+     * the launch computes  C = LN(x) . W^T + b  (F.layer_norm over the K channels, eps = ln_eps, followed by F.linear: the norm1 -> to_q / to_k /
+     * to_v, norm2 -> to_q and norm3 -> ff.net.0.proj pairs of diffusers' BasicTransformerBlock under src/pix2pix_turbo.py:199) as
+     *     C[m][n] = rstd_m * (x_m . W'_n) - rstd_m * mu_m * ln_cs[n] + bias[n],
+     * with W'[n][k] = W[n][k] * gamma[k] in `b` (folded by i2i_lora_merge: kscale), ln_cs[n] = sum_k W'[n][k] over the STORED (rounded)
+     * weights and bias[n] = b[n] + sum_k W[n][k] * beta[k] (both written by i2i_lora_merge).  mu_m / rstd_m are accumulated from the row
+     * fragments in the K loop (no extra pass over x, no normalised copy of x in HBM).  NULL = off. */
+    const float* ln_cs; float ln_eps;
+    /* Transposed column range (with ln_cs only): output columns n >= n_trans are written TRANSPOSED to c2[(n - n_trans) * ldc2 + m]
+     * (the self-attention V^T [C][B*T] the flash kernel reads), columns below it to `c` as usual: to_q | to_k | to_v in ONE launch.
+     * n_trans a multiple of the tile width (160 / 128), M a multiple of 8; 0 = off. */
+    int32_t n_trans; void* c2; int32_t ldc2;
 } i2i_igemm_params;
 
 /* GroupNorm statistics -> per (image, channel) (scale, shift) so that GN(x)[c] = x*scale + shift.
@@ -135,7 +149,12 @@ typedef struct {
     int32_t* counters;                        /* optional (ABI v7), >= nimg*groups ints, ZERO before the first launch (the kernel leaves
                                                  them zero): lets the single-launch path for small tensors cut every image's pixels
                                                  into up to `nparts` slices, one workgroup each; the workgroup that arrives last at
-                                                 its (image, group set) ticket sums the slices in a fixed order and writes `ss` */
+                                                 its (image, group set) ticket sums the slices in a fixed order and writes `ss`.
+                                                 CONCURRENCY: `counters` / `partial` are state of the launch in flight -- an op (and therefore
+                                                 a program, a captured graph or a loaded plan file that contains it) must not run on two
+                                                 streams at once; consecutive launches on one stream are fine (the kernel leaves the
+                                                 counters at zero).  The same holds for every scratch slab an op names (gn_part, ws,
+                                                 i2i_gn_norm_params.partial). */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its
@@ -223,6 +242,13 @@ typedef struct {
     void* dst; const float* w0; const float* a; const float* b;
     int32_t N, K, rank, use_gamma;
     const float* rg;
+    /* LayerNorm fold (ABI v9, all NULL = off): the consumer GEMM computes LN(x) . W^T from the un-normalised rows (i2i_igemm_params.ln_cs):
+     *   dst[n][k]   = cvt( w'[n][k] * kscale[k] ),  w' = (w0 + r b.a) * g as above, kscale = the LayerNorm weight
+     *   colsum[n]   = sum_k float(dst[n][k])                 (of the ROUNDED values: a constant row then cancels exactly)
+     *   bias_out[n] = (bias0 ? bias0[n] : 0) + sum_k w'[n][k] * kshift[k],   kshift = the LayerNorm bias
+     * summed per row in a fixed order (deterministic, r -> r' -> r reproduces the bits). */
+    const float* kscale; const float* kshift; const float* bias0;
+    float* colsum; float* bias_out;
 } i2i_lora_merge_params;
 
 /* One separable pass of Pillow's LANCZOS resampling on uint8 HWC image batches [n][hin][win][c] (c <= 4), bit-identical to
@@ -236,6 +262,22 @@ typedef struct {
     int32_t nout, ksize;       /* output extent along `axis`; weights per output coordinate */
     const int32_t* bounds; const int32_t* coeffs;
 } i2i_resize_u8_params;
+
+/* GroupNorm (+ SiLU) as ONE op: statistics and apply (ABI v9).  y = act(F.group_norm(cat(x0, x1), groups, gamma, beta, eps)) written as one
+ * [nimg][hw][ldy] tensor: what the consumers that stage their operand by LDS-DMA read (the UNet's 3x3 convolutions and proj_in on the
+ * wide GEMM).  Replaces the I2I_OP_GN_STATS + I2I_OP_GN_APPLY (x2 for a concat) chain by two lean launches: every image is cut into
+ * `nslices` pixel slices (i2i_gn_norm_slices()); launch 1 stores each slice's per-group SHIFTED sums (pivot = the group's first channel at
+ * pixel 0, so that E[d^2] - E[d]^2 never cancels: no second pass), launch 2 sums them in slice order (deterministic), builds every
+ * channel's (scale, shift) and normalises the slice's pixels of both sources.  `partial`: nimg*nslices*groups*2 floats of scratch. */
+typedef struct {
+    const void* x0; const void* x1; int32_t c0, c1, ld0, ld1;
+    int32_t nimg, hw, groups; float eps;
+    const float* gamma; const float* beta;    /* [c0+c1] fp32 */
+    void* y; int32_t ldy; int32_t act;        /* act: 0 none, 1 SiLU */
+    float* partial; int32_t nslices;
+} i2i_gn_norm_params;
+
+typedef struct { int32_t unused; } i2i_nop_params;
 
 typedef struct {
     int32_t opcode;    /* i2i_opcode */
@@ -254,6 +296,8 @@ typedef struct {
         i2i_embed_params embed;
         i2i_lora_merge_params lora_merge;
         i2i_resize_u8_params resize_u8;
+        i2i_gn_norm_params gn_norm;
+        i2i_nop_params nop;
     } u;
 } i2i_op;
 
@@ -274,6 +318,9 @@ int i2i_igemm_gn_parts(const i2i_igemm_params* p, int dtype, int groups);
 const char* i2i_igemm_route(const i2i_igemm_params* p, int dtype);
 int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);
 int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream);
+int i2i_gn_norm(const i2i_gn_norm_params* p, int dtype, void* stream);
+/* Pixel slices per image i2i_gn_norm() wants for this shape (planner query: sizes `partial`; launches nothing). */
+int i2i_gn_norm_slices(int nimg, int hw, int channels);
 int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream);
 int i2i_softmax(const i2i_softmax_params* p, int dtype, void* stream);
 int i2i_attention(const i2i_attention_params* p, int dtype, void* stream);
@@ -284,6 +331,15 @@ int i2i_ddpm_postquant(const i2i_ddpm_params* p, int dtype, void* stream);
 int i2i_embed(const i2i_embed_params* p, int dtype, void* stream);
 int i2i_lora_merge(const i2i_lora_merge_params* p, int dtype, void* stream);
 int i2i_resize_u8(const i2i_resize_u8_params* p, int dtype, void* stream);   /* dtype ignored (uint8 data) */
+
+/* ---- calibration micro-kernels (csrc/calib.hip; bench.py's `calib` block: what THIS box delivers on three elementary loads, so that
+ * lines measured on different boxes of a pool can be compared).  Not on the forward path. */
+int i2i_nop(void* stream);                                                         /* one empty kernel (1 wave) */
+/* 1024 waves (one per SIMD) each issue `iters` x 8 independent v_mfma_f32_32x32x16 on operands read from `operands` (>= 64 KiB of dtype
+ * data, random for a power-realistic reading); FLOPs = 1024 * iters * 8 * 32768.  `sink`: >= 1024*64 floats (keeps the work alive). */
+int i2i_calib_mfma(int dtype, int iters, const void* operands, float* sink, void* stream);
+/* dst[i] = src[i] over `bytes` (multiple of 16), 16 bytes per lane, grid-stride: 2 * bytes of HBM traffic */
+int i2i_calib_stream(const void* src, void* dst, size_t bytes, void* stream);
 
 /* ---- programs: a forward pass is a flat array of ops executed in order on one stream ---- */
 int i2i_run(const i2i_op* ops, int n_ops, void* stream);

@@ -25,4 +25,5 @@ void rt_free(void* p) { free(p); }
 int rt_upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 int rt_download(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 int rt_zero(void* dst, size_t bytes) { memset(dst, 0, bytes); return 0; }
+int rt_sync() { return 0; }
 }  // namespace i2i

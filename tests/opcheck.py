@@ -441,3 +441,99 @@ def check_u8_boundary(lib, device, dtype, *, n=2, h=6, w=10, seed=0):
     run_op(lib, opcode, p, dtype, device)
     exp = ((xd.cpu().float()[..., :3].clamp(-1, 1) * 0.5 + 0.5).clamp(0, 1) * 255.0).to(torch.uint8)
     assert (out.cpu().int() - exp.int()).abs().max() <= (0 if dtype == torch.float32 else 1)
+
+
+def check_ln_gemm(lib, device, dtype, *, rows=200, cin=128, nq=160, nv=0, geglu=False, tile=52, lora_rank=4, r=0.7, seed=0, offset=0.0):
+    """LayerNorm folded into the wide GEMM (i2i_igemm_params.ln_cs) together with the device-side merge that prepares its operands
+    (i2i_lora_merge_params.kscale ..): out = F.linear(F.layer_norm(x), W + r B.A, b) from the UN-normalised rows, `nv` further
+    output columns written transposed (the V^T of a self-attention block), or the GEGLU form.  Reference: plain fp32 torch on the
+    rounded inputs, LayerNorm output NOT rounded (the kernel never materialises it)."""
+    g = torch.Generator().manual_seed(seed)
+    N = nq + nv
+    x = (torch.randn(rows, cin, generator=g) * 1.3 + offset + 0.2 * torch.randn(rows, 1, generator=g)).to(dtype)
+    W = torch.randn(N, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(N, generator=g) * 0.1
+    A = torch.randn(lora_rank, cin, generator=g) / math.sqrt(cin)
+    Bm = torch.randn(N, lora_rank, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(cin, generator=g)
+    beta = 0.2 * torch.randn(cin, generator=g)
+    Wm = W + r * (Bm @ A)
+    if geglu:
+        half = N // 2
+        idx = torch.arange(half).reshape(-1, 16)
+        idx = torch.cat([idx, idx + half], 1).reshape(-1)
+        Wp, bp, Bp = W[idx], b[idx], Bm[idx]
+    else:
+        Wp, bp, Bp = W, b, Bm
+    dev = lambda t, dt=torch.float32: t.to(dt).contiguous().to(device)
+    wd = torch.zeros(N, cin, dtype=dtype, device=device)
+    cs = torch.full((N,), float("nan"), device=device)
+    bout = torch.full((N,), float("nan"), device=device)
+    rg = dev(torch.tensor([r, 1.0]))
+    mp = K.LoraMergeParams()
+    keep = [dev(Wp), dev(A), dev(Bp), dev(gamma), dev(beta), dev(bp)]
+    mp.dst, mp.w0, mp.a, mp.b, mp.N, mp.K, mp.rank, mp.use_gamma, mp.rg = wd.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), N, cin, lora_rank, 0, rg.data_ptr()
+    mp.kscale, mp.kshift, mp.bias0, mp.colsum, mp.bias_out = keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), cs.data_ptr(), bout.data_ptr()
+    run_op(lib, K.OP_LORA_MERGE, mp, dtype, device)
+    # the merge: stored weights = cvt(W' * gamma), colsum of the STORED values, bias' = b + W'.beta
+    wq = (Wm * gamma[None]).to(dtype)
+    wref = wq[idx] if geglu else wq
+    assert rel_err(wd.cpu(), wref) < (1e-6 if dtype == torch.float32 else 1e-2), "ln-fold merge: weights"
+    assert rel_err(cs.cpu(), wd.cpu().float().sum(1)) < 1e-5, "ln-fold merge: column sums"
+    bref = b + Wm @ beta
+    assert rel_err(bout.cpu(), bref[idx] if geglu else bref) < 1e-5, "ln-fold merge: bias"
+    # the GEMM
+    xd = x.to(device)
+    n_out = N // 2 if geglu else nq
+    out = torch.full((rows, n_out), float("nan"), dtype=dtype, device=device)
+    out2 = torch.full((max(nv, 1), rows), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.conv(xd, wd, out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=N, bias=bout, ldc=n_out, geglu=int(geglu), tile=tile)
+    p.ln_cs, p.ln_eps = cs.data_ptr(), 1e-5
+    if nv:
+        p.n_trans, p.c2, p.ldc2 = nq, out2.data_ptr(), rows
+    assert lib.igemm_route(p, O.DT[dtype]) == "gemm_w32_kernel"
+    run_op(lib, opcode, p, dtype, device)
+    y = F.layer_norm(x.float(), (cin,), gamma, beta, 1e-5)
+    full = y @ wq.float().T / gamma.new_ones(1) * 1.0     # LN(x) . (W' gamma)^T / gamma is NOT what runs: restate exactly below
+    full = ((x.float() - x.float().mean(1, keepdim=True)) * torch.rsqrt(x.float().var(1, unbiased=False, keepdim=True) + 1e-5)) @ wq.float().T + bref[None]
+    if geglu:
+        ref = full[:, :half] * F.gelu(full[:, half:])
+        err = rel_err(out.cpu(), ref)
+    else:
+        err = rel_err(out.cpu(), full[:, :nq])
+        if nv:
+            err = max(err, rel_err(out2.cpu(), full[:, nq:].T))
+    assert err < TOL[dtype], f"ln gemm rel err {err}"
+    return err
+
+
+def check_gn_norm(lib, device, dtype, *, n=2, c0=32, c1=0, h=9, w=7, groups=8, act=1, eps=1e-5, seed=0, offset=0.0, slices=None):
+    """GroupNorm statistics + apply (+ SiLU) as one op (i2i_gn_norm) against F.group_norm on the rounded input; a second run must give
+    the same bits."""
+    g = torch.Generator().manual_seed(seed)
+    ct = c0 + c1
+    x = torch.randn(n, ct, h, w, generator=g) * 1.5 + 0.3 + offset
+    gamma = 1 + 0.1 * torch.randn(ct, generator=g)
+    beta = 0.1 * torch.randn(ct, generator=g)
+    xq = x.to(dtype).float()
+    ref = F.group_norm(xq.double(), groups, gamma.double(), beta.double(), eps).float()
+    if act:
+        ref = F.silu(ref)
+    x0 = nhwc(x[:, :c0], dtype).to(device)
+    x1 = nhwc(x[:, c0:], dtype).to(device) if c1 else None
+    S = slices or int(lib.lib.i2i_gn_norm_slices(n, h * w, ct))
+    partial = torch.zeros(n * S * groups * 2, device=device)
+    y = torch.full((n, h, w, ct), float("nan"), dtype=dtype, device=device)
+    gd, bd = gamma.to(device), beta.to(device)
+    opcode, p = O.gn_norm(x0, y, gd, bd, partial, nimg=n, hw=h * w, groups=groups, eps=eps, act=act, nslices=S,
+                          x1=x1, c0=c0, c1=c1, ld0=c0, ld1=c1, ldy=ct)
+    run_op(lib, opcode, p, dtype, device)
+    got = y.cpu().float().permute(0, 3, 1, 2)
+    err = float((got - ref).abs().max())
+    tol = {torch.float32: 2e-4, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype] * max(1.0, float(ref.abs().max()))
+    assert err < tol, f"gn_norm abs err {err} (tol {tol})"
+    first = y.clone()
+    y.fill_(float("nan"))
+    run_op(lib, opcode, p, dtype, device)
+    assert torch.equal(y, first), "gn_norm is not run-to-run identical"
+    return err

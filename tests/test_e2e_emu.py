@@ -50,6 +50,31 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     _check_plan_file_round_trip(emu_lib, model, x, cap, eps, nm, out)
 
 
+@pytest.mark.slow
+def test_mixed_precision_plan_fp16_unet_bf16_vae(emu_lib):
+    """Per-network precision (Pix2Pix_Turbo(dtype=bf16, unet_dtype=fp16)): the VAE's ops are recorded as bf16, the UNet's as fp16, the two
+    meet in fp32 (posterior latents in, eps-prediction out).  The error against the fp32 oracle lies between the all-bf16 and the
+    all-fp16 plan's -- the UNet's error is what the 1-step scheduler multiplies by 14.6."""
+    from img2img_turbo_amd import _capi as K
+    mw = make_pix2pix_weights(TINY_UNET, TINY_VAE, seed=3)
+    x, cap, eps, _ = make_inputs("canny", 1, 64, 64, TINY_UNET.cross_attention_dim)
+    ref = pix2pix_forward(mw, x, cap, eps)
+    errs = {}
+    for name, kw in (("bf16", dict(dtype=torch.bfloat16)), ("mixed", dict(dtype=torch.bfloat16, unet_dtype=torch.float16)), ("f16", dict(dtype=torch.float16))):
+        model = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", lib=emu_lib, **kw)
+        out = model(x, caption_enc=cap, eps=eps)
+        errs[name] = ((out.float() - ref) ** 2).mean().sqrt().item()
+        if name == "mixed":
+            plan = list(model._plans.values())[0]
+            dts = {}
+            for (opc, dt, _p, label) in plan.prog.ops:
+                net = "vae" if label.startswith(("encoder", "decoder", "input", "output", "ddpm")) else "unet"
+                dts.setdefault(net, set()).add(dt)
+            assert dts["vae"] == {K.BF16} and dts["unet"] == {K.F16}, dts
+            assert plan.ctx.dtype == torch.float16 and plan.out.dtype == torch.bfloat16
+    assert errs["f16"] < errs["mixed"] < errs["bf16"], errs
+
+
 def _check_plan_file_round_trip(lib, model, x, cap, eps, nm, out_python, c_host=True, plan=None):
     """The whole-forward entry for hosts that are not Python (include/i2i_turbo.h i2i_plan_*): the planned forward is written to a plan
     file, loaded by the C library into its OWN buffers (nothing of the Python plan is shared: every pointer is relocated), fed through
@@ -251,9 +276,35 @@ def test_two_plans_with_different_r_interleave_and_released_plan_refuses(emu_lib
     model.stage(ps, x, cap, eps, nm)
     ps.run()
     assert (ps.out - ref_s).abs().max().item() < 1e-3
-    model.release_plans()
-    with pytest.raises(RuntimeError):
-        ps.run()
+    # Exporting a plan file reads the SHARED packed weights back: the stochastic plan exported after a deterministic plan moved the device
+    # state to r = 1 must still carry ITS r (export_plan re-merges through plan._prepare), i.e. the loaded file reproduces the r = 0.4
+    # replay bit for bit -- and a released plan refuses to export.
+    import os
+    import tempfile
+    from img2img_turbo_amd.plan_file import export_plan
+    out_s = ps.out.clone()
+    pd = model.get_plan(1, 64, 64)                                    # deterministic plan: running it re-merges at r = 1
+    model.stage(pd, x, cap, eps, None)
+    pd.run()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "stochastic_after_deterministic.i2iplan")
+        export_plan(ps, path)
+        h = emu_lib.plan_load(path)
+        try:
+            emu_lib.plan_write(h, "x", x.contiguous())
+            emu_lib.plan_write(h, "ctx", cap.to(ps.ctx.dtype).reshape(ps.ctx.shape).contiguous())
+            emu_lib.plan_write(h, "eps", eps.contiguous())
+            emu_lib.plan_write(h, "noise", nm.expand_as(ps.noise).contiguous())
+            emu_lib.plan_run(h)
+            got = emu_lib.plan_read(h, "out", torch.empty_like(ps.out))
+        finally:
+            emu_lib.plan_destroy(h)
+        assert torch.equal(got, out_s), float((got - out_s).abs().max())
+        model.release_plans()
+        with pytest.raises(RuntimeError):
+            ps.run()
+        with pytest.raises(RuntimeError):
+            export_plan(ps, path)
 
 
 @pytest.mark.slow

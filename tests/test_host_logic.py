@@ -413,6 +413,62 @@ def test_data_parallel_forward_two_ranks_gloo(tmp_path, emu_lib):
     assert "DP_E2E_OK" in outs[0]
 
 
+_SHARED_WEIGHTS_WORKER = r"""
+import hashlib, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "tests", "emu"))
+import build_emu
+from img2img_turbo_amd import _capi, dp
+from img2img_turbo_amd.arch import TINY_UNET, TINY_VAE
+from img2img_turbo_amd.packer import Packer
+from img2img_turbo_amd.synth import make_cyclegan_weights
+rank, world, local = dp.init_from_env("gloo")
+built = []
+def build():
+    built.append(rank)
+    return make_cyclegan_weights(TINY_UNET, TINY_VAE, seed=11, rank_unet=16)
+w = dp.shared_weights(build, rank, world, tag="test")
+assert built == ([0] if rank == 0 else []), built                   # only rank 0 ran the builder
+ref = make_cyclegan_weights(TINY_UNET, TINY_VAE, seed=11, rank_unet=16)
+for a, b in ((w.unet, ref.unet), (w.vae, ref.vae), (w.vae_b2a, ref.vae_b2a)):
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+assert w.unet_arch == ref.unet_arch and w.vae_arch == ref.vae_arch and w.unet_scaling == ref.unet_scaling and w.vae_scaling == ref.vae_scaling
+# ... and what every rank PACKS from them (device-side LoRA merge on the emulated kernels) is the same bytes
+lib = _capi.Library(build_emu.build())
+pk = Packer(w.unet, w.unet_scaling, torch.bfloat16, "cpu", lib, 0.7, 0.7)
+h = hashlib.sha256()
+for name in ("down_blocks.0.resnets.0.conv1", "mid_block.attentions.0.proj_in"):
+    h.update(pk.conv(name)["w"].view(torch.uint8).numpy().tobytes())
+t = "down_blocks.1.attentions.0.transformer_blocks.0"
+for ent in (pk.ln_linear([t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"], t + ".norm1"), pk.ln_linear([t + ".ff.net.0.proj"], t + ".norm3", geglu=True)):
+    for k in ("w", "b", "cs"):
+        h.update(ent[k].contiguous().view(torch.uint8).numpy().tobytes())
+mine = torch.tensor(list(h.digest()), dtype=torch.uint8)
+all_ = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(all_, mine)
+assert all(torch.equal(all_[0], x) for x in all_), "ranks packed different bytes"
+assert not [f for f in os.listdir("/dev/shm") if f.startswith("i2i_test_")], "the shared file must be unlinked once every rank mapped it"
+dp.barrier()
+if rank == 0:
+    print("SHARED_WEIGHTS_OK")
+"""
+
+
+@pytest.mark.slow
+def test_shared_weights_one_builder_all_ranks_identical(tmp_path, emu_lib):
+    """N > 1 set-up: the weights are built ONCE (rank 0) and shared through a /dev/shm safetensors file; every rank
+    then holds bit-identical host weights and packs bit-identical device tensors (incl. the LayerNorm-folded layers)."""
+    script = tmp_path / "shared_w.py"
+    script.write_text(_SHARED_WEIGHTS_WORKER % (ROOT, ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29763", WORLD_SIZE="2")
+    env.pop("I2I_EMU_ASYNC", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARED_WEIGHTS_OK" in outs[0]
+
+
 @pytest.mark.slow
 def test_bench_two_ranks_on_the_emulator(emu_lib, extra=()):
     """`bench.py --gpus 2` end to end without a GPU: two gloo ranks on the CPU wave emulator (bench.py --emulate, a test hook) go

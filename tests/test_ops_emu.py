@@ -556,3 +556,50 @@ def test_gemm_w32_routing(emu_lib):
         assert emu_lib.igemm_route(mk(), K.BF16) == "igemm_dma_kernel"
     finally:
         del os.environ["I2I_GEMM_W32"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gn_norm_one_launch(emu_lib, dtype):
+    """GroupNorm statistics + apply as one op (slice statistics launch, finalize-and-apply launch)."""
+    oc.check_gn_norm(emu_lib, "cpu", dtype)
+    oc.check_gn_norm(emu_lib, "cpu", dtype, c0=40, c1=24, groups=4, h=5, w=5)                 # two sources, a group straddles the seam
+    oc.check_gn_norm(emu_lib, "cpu", dtype, c0=320, groups=32, h=8, w=8, n=1, act=0)          # cpg 10
+
+
+def test_gn_norm_wide_and_offset(emu_lib):
+    oc.check_gn_norm(emu_lib, "cpu", torch.float32, c0=1280, c1=1280, groups=32, h=4, w=4, n=1)      # two unit rounds per thread
+    oc.check_gn_norm(emu_lib, "cpu", torch.float32, offset=100.0, h=16, w=16)                         # shifted sums: no cancellation
+    oc.check_gn_norm(emu_lib, "cpu", torch.bfloat16, n=3, c0=64, h=9, w=11, groups=8, slices=5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_folded_into_the_wide_gemm(emu_lib, dtype):
+    oc.check_ln_gemm(emu_lib, "cpu", dtype)
+    oc.check_ln_gemm(emu_lib, "cpu", dtype, nq=320, nv=160, rows=264)                          # to_q | to_k | to_v^T in one launch
+    oc.check_ln_gemm(emu_lib, "cpu", dtype, nq=256, nv=128, rows=136, tile=54, cin=64)
+    oc.check_ln_gemm(emu_lib, "cpu", dtype, nq=320, geglu=True, tile=55)
+    oc.check_ln_gemm(emu_lib, "cpu", dtype, nq=256, rows=300, tile=53, offset=5.0, lora_rank=0)
+
+
+def test_layernorm_fold_is_refused_off_the_wide_gemm(emu_lib):
+    """An op that carries ln_cs must never run on a kernel that would ignore it."""
+    x = torch.zeros(64, 64, dtype=torch.float32)
+    w = torch.zeros(32, 64, dtype=torch.float32)
+    out = torch.zeros(64, 32, dtype=torch.float32)
+    cs = torch.zeros(32)
+    opcode, p = O.conv(x, w, out, nimg=1, hin=1, win=64, ho=1, wo=64, ks=1, c0=64, lda0=64, N=32, bias=cs, ldc=32)
+    p.ln_cs, p.ln_eps = cs.data_ptr(), 1e-5
+    prog = K.Program()
+    prog.add(opcode, K.F32, p)
+    prog.freeze()
+    with pytest.raises(K.I2IError):
+        emu_lib.run(prog, 0)
+
+
+def test_gn_stats_flag_boundaries(emu_lib):
+    """Both sides of the dtype-aware second-pass ratios (csrc/norm.hip GnRefine: mu^2 / var > 2048 for fp16, 16384 for bf16): just under
+    the ratio the one-pass numbers must stay within one rounding step of the storage type, just above it the second pass runs."""
+    for dtype, lo, hi in ((torch.bfloat16, 118.0, 136.0), (torch.float16, 43.0, 48.0)):
+        for mean in (lo, hi):
+            oc.check_gn_stats_offset(emu_lib, "cpu", dtype, h=24, w=20, mean=mean, std=1.0, finalize_only=True, nparts=96)
+            oc.check_gn_stats_offset(emu_lib, "cpu", dtype, h=24, w=20, mean=mean, std=1.0)

@@ -320,3 +320,43 @@ def test_gn_stats_large_offset_second_pass(gpu_lib):
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.bfloat16, n=2, c=128, h=128, w=128, groups=32, mean=100.0, std=0.3, nparts=512, finalize_only=True)   # above bf16's flag ratio
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=2, c=320, h=64, w=64, groups=32, mean=200.0, std=0.2)          # cpg 10 (UNet): 4-byte pieces
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=1, c=512, h=64, w=64, groups=32, mean=200.0, std=0.2, nparts=16)   # cpg 16: 16-byte pieces
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gn_norm_one_launch(gpu_lib, dtype):
+    """GroupNorm statistics + apply as one op (i2i_gn_norm): the UNet's resnet / transformer inputs at batch 1 and 8, concat inputs
+    whose groups straddle the two sources, a tensor on a DC offset (the shifted sums must not cancel), several slice counts."""
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=320, h=64, w=64, groups=32)
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=1, c0=320, h=64, w=64, groups=32)
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=640, c1=320, h=64, w=64, groups=32)          # cpg 30: groups straddle the seam
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=1, c0=1280, c1=1280, h=8, w=8, groups=32)          # two unit rounds per thread
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=1280, c1=640, h=16, w=16, groups=32, act=0)
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=3, c0=640, h=33, w=41, groups=32)                  # ragged slices
+    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=2, c0=128, h=48, w=40, groups=32, offset=100.0)
+    for s in (1, 2, 7, 32, 64):
+        oc.check_gn_norm(gpu_lib, "cuda", dtype, n=2, c0=320, h=32, w=32, groups=32, slices=s, seed=s)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_folded_into_the_wide_gemm(gpu_lib, dtype):
+    """LayerNorm + linear in one launch (i2i_igemm_params.ln_cs) incl. the merge that folds the LayerNorm weight: every tile
+    configuration, the to_q | to_k | to_v^T form (transposed column range), the GEGLU form, SD-Turbo's three widths, rows on a DC offset."""
+    for tile in (51, 52, 53, 54):
+        wide = 160 if tile in (51, 52) else 128
+        oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=1000, cin=320, nq=4 * wide, tile=tile)
+        oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=1000, cin=320, nq=4 * wide, nv=2 * wide, tile=tile, seed=1)
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=4096, cin=320, nq=640, nv=320, tile=50)
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=1024, cin=640, nq=1280, nv=640, tile=50)
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=264, cin=1280, nq=2560, nv=1280, tile=50)
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=64, cin=1280, nq=1280, tile=50)                       # cross-attention to_q at batch 1
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=777, cin=320, nq=2560, geglu=True, tile=50)           # -> the two-workgroups-per-CU form
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=520, cin=1280, nq=10240, geglu=True, tile=50)
+    oc.check_ln_gemm(gpu_lib, "cuda", dtype, rows=512, cin=640, nq=640, tile=50, offset=8.0, seed=3)
+
+
+def test_gn_stats_flag_boundaries(gpu_lib):
+    """Both sides of the dtype-aware second-pass ratios (csrc/norm.hip GnRefine) with epilogue-style partial sums (512 parts)."""
+    for dtype, lo, hi in ((torch.bfloat16, 118.0, 136.0), (torch.float16, 43.0, 48.0)):
+        for mean in (lo, hi):
+            oc.check_gn_stats_offset(gpu_lib, "cuda", dtype, h=64, w=64, mean=mean, std=1.0, finalize_only=True, nparts=512)
+            oc.check_gn_stats_offset(gpu_lib, "cuda", dtype, h=64, w=64, mean=mean, std=1.0, sliced=True, nparts=20)
