@@ -16,7 +16,7 @@ OP_IGEMM, OP_GN_STATS, OP_LAYERNORM, OP_SOFTMAX = 1, 2, 3, 4
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_POSTERIOR, OP_DDPM_POSTQUANT, OP_ATTENTION, OP_GN_APPLY, OP_EMBED = 5, 6, 7, 8, 9, 10, 11
 OP_LORA_MERGE = 12
 OP_RESIZE_U8 = 13
-OP_GN_NORM, OP_NOP = 14, 15
+OP_NOP = 14
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 ABI_VERSION = 9          # include/i2i_turbo.h I2I_ABI_VERSION this binding was written for
@@ -101,12 +101,6 @@ class ResizeU8Params(C.Structure):
                 ("bounds", vp), ("coeffs", vp)]
 
 
-class GnNormParams(C.Structure):
-    _fields_ = [("x0", vp), ("x1", vp), ("c0", i32), ("c1", i32), ("ld0", i32), ("ld1", i32),
-                ("nimg", i32), ("hw", i32), ("groups", i32), ("eps", f32), ("gamma", vp), ("beta", vp),
-                ("y", vp), ("ldy", i32), ("act", i32), ("partial", vp), ("nslices", i32)]
-
-
 class NopParams(C.Structure):
     _fields_ = [("unused", i32)]
 
@@ -116,7 +110,7 @@ class _OpUnion(C.Union):
                 ("layernorm", LayerNormParams), ("softmax", SoftmaxParams), ("attention", AttentionParams),
                 ("to_nhwc", NchwToNhwcParams), ("to_nchw", NhwcToNchwParams), ("embed", EmbedParams),
                 ("posterior", PosteriorParams), ("ddpm", DdpmParams), ("lora_merge", LoraMergeParams), ("resize_u8", ResizeU8Params),
-                ("gn_norm", GnNormParams), ("nop", NopParams)]
+                ("nop", NopParams)]
 
 
 class Op(C.Structure):
@@ -126,10 +120,10 @@ class Op(C.Structure):
 _FIELD_OF = {OP_IGEMM: "igemm", OP_GN_STATS: "gn_stats", OP_GN_APPLY: "gn_apply", OP_LAYERNORM: "layernorm",
              OP_SOFTMAX: "softmax", OP_ATTENTION: "attention", OP_NCHW_TO_NHWC: "to_nhwc",
              OP_NHWC_TO_NCHW: "to_nchw", OP_POSTERIOR: "posterior", OP_DDPM_POSTQUANT: "ddpm", OP_EMBED: "embed",
-             OP_LORA_MERGE: "lora_merge", OP_RESIZE_U8: "resize_u8", OP_GN_NORM: "gn_norm", OP_NOP: "nop"}
+             OP_LORA_MERGE: "lora_merge", OP_RESIZE_U8: "resize_u8", OP_NOP: "nop"}
 
 EXPORTS = ["i2i_abi_version", "i2i_backend", "i2i_last_error", "i2i_sizeof_op", "i2i_igemm", "i2i_igemm_gn_parts", "i2i_igemm_route", "i2i_gn_stats",
-           "i2i_gn_apply", "i2i_gn_norm", "i2i_gn_norm_slices", "i2i_nop", "i2i_calib_mfma", "i2i_calib_stream", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
+           "i2i_gn_apply", "i2i_nop", "i2i_calib_mfma", "i2i_calib_stream", "i2i_layernorm", "i2i_softmax", "i2i_attention", "i2i_nchw_to_nhwc",
            "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8", "i2i_run", "i2i_run_timed",
            "i2i_graph_create", "i2i_graph_launch", "i2i_graph_destroy",
            "i2i_plan_load", "i2i_plan_io", "i2i_plan_write", "i2i_plan_read", "i2i_plan_ops", "i2i_plan_run", "i2i_plan_destroy"]
@@ -183,12 +177,10 @@ class Library:
         L.i2i_backend.restype = C.c_char_p
         L.i2i_last_error.restype = C.c_char_p
         L.i2i_sizeof_op.restype = C.c_size_t
-        for name in ("i2i_igemm", "i2i_gn_stats", "i2i_gn_apply", "i2i_gn_norm", "i2i_layernorm", "i2i_softmax", "i2i_attention",
+        for name in ("i2i_igemm", "i2i_gn_stats", "i2i_gn_apply", "i2i_layernorm", "i2i_softmax", "i2i_attention",
                      "i2i_nchw_to_nhwc", "i2i_nhwc_to_nchw", "i2i_posterior", "i2i_ddpm_postquant", "i2i_embed", "i2i_lora_merge", "i2i_resize_u8"):
             getattr(L, name).argtypes = [vp, C.c_int, vp]
             getattr(L, name).restype = C.c_int
-        L.i2i_gn_norm_slices.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.i2i_gn_norm_slices.restype = C.c_int
         L.i2i_nop.argtypes = [vp]
         L.i2i_calib_mfma.argtypes = [C.c_int, C.c_int, vp, vp, vp]
         L.i2i_calib_stream.argtypes = [vp, vp, C.c_size_t, vp]

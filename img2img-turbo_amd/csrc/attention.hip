@@ -193,9 +193,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const i2i_attention_para
 //     LDS traffic per FLOP of the 16-query version; workgroup = 4 waves = 128 queries;
 //   * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] (8 KiB each) arrive by global_load_lds_dwordx4 into a
 //     3-stage ring, issued two tiles ahead, waited for with a counted vmcnt; ONE raw barrier per key tile;
-//   * scores are scaled by scale*log2(e) once and exponentiated with v_exp_f32 (2^x) directly;
 //   * rows / chunks past tk read a 16-byte zero block; the partially valid last V^T chunk (tk % 8 != 0) is cleaned
 //     in LDS before use (its padding may hold anything, and 0 * NaN would poison the output).
+// Round 6: the softmax between the two contractions was the bound of this kernel (profiles/r5g_pmc_attention_summary.txt: matrix
+// pipe 21 % busy; ~280 VALU instructions per wave and key tile against 32 MFMAs), so the work per score is cut to what cannot be
+// avoided -- one v_max3 per two scores, one v_exp, one v_cvt_pk per two:
+//   * scores leave the MFMA in log2 units (scale * log2(e) rides in q: the model's to_q epilogue produces q pre-multiplied and
+//     passes scale = ln 2; any other caller's q is multiplied once at load) and ALREADY SHIFTED by the running reference of their
+//     query: the accumulator of the first MFMA of a score fragment starts from -m_ref instead of 0;
+//   * the reference is LAZY: it only moves when some score of the tile exceeds it by more than 2^8 (wave-uniform test on the
+//     lane-local maxima, no cross-lane traffic); then -- and on the first tile -- the slow path finds the query maxima, shifts the
+//     tile's scores and rescales O and the row sums.  Softmax is shift invariant, so any reference is exact as long as nothing
+//     overflows: P <= 2^8 in bf16 / fp16 keeps its relative precision, O and the sums accumulate in fp32;
+//   * the row sums come out of the matrix pipe: one more MFMA per 32 keys against an all-ones A fragment leaves the sum of the
+//     ROUNDED probabilities of query lr in every lane of its column (the same numbers the P.V product uses), no per-score add and
+//     no final quad reduction;
+//   * keys are taken in a permuted order inside a tile -- row m of score fragment kf is key 32(kf >> 1) + 8(m >> 2) + 4(kf & 1) +
+//     (m & 3) -- so that the eight probabilities a lane packs for the second contraction are eight CONSECUTIVE keys: its V^T
+//     operand is one ds_read_b128 (it was two ds_read_b64 plus register moves).  The K tile's XOR swizzle is chosen for that row
+//     pattern (att_kswz: the 16 rows of a fragment read hit 16 distinct 16-byte slots).
 // XCD-aware workgroup order for the DMA attention kernels (1-D grid; workgroup id -> XCD id % 8): every (batch, head)
 // group keeps all its query tiles on ONE XCD, so its K / V^T tiles are fetched into that XCD's L2 once and hit by the
 // other query tiles, instead of every XCD streaming every group from the fabric.  Groups g, g + 8, ... share an XCD
@@ -212,11 +228,18 @@ inline unsigned att_grid(int nqt, int heads, int batch) { return (unsigned)(((he
 
 __device__ __attribute__((aligned(16))) uint32_t g_att_zero16[4] = {0u, 0u, 0u, 0u};
 
+// attention_dma_kernel's K tile: rows of 8 chunks, chunk kc of row r at physical chunk kc ^ att_kswz(r)
+__device__ __forceinline__ int att_kswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+__device__ __forceinline__ int att_koff(int row, int kc) { return row * 128 + ((kc ^ att_kswz(row)) << 4); }
+// the key (inside its 64-key tile) that row m of score fragment kf holds
+__device__ __forceinline__ int att_key_of(int kf, int m) { return 32 * (kf >> 1) + 8 * (m >> 2) + 4 * (kf & 1) + (m & 3); }
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attention_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit types only");
     constexpr int D = 64, BKV = 64, QF = 2, STAGE = 2 * BKV * 128, PPW = 4;   // 16 one-KiB pieces per stage, 4 per wave
+    constexpr float LAZY = 8.0f;                                              // log2 units a score may exceed its reference by
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     int qt, h, b;
@@ -236,12 +259,15 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     // chunks past the end come from a zero block (the partially valid chunk is cleaned in LDS below).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool k_wave = wave_u < 2;
+    auto src_chunk = [&](int row) __attribute__((always_inline)) {           // source chunk of physical chunk lane & 7
+        return (lane & 7) ^ (k_wave ? att_kswz(row) : ((row >> 1) & 7));
+    };
     unsigned d_off[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int pc = wave_u * PPW + q;
         const int row = (pc & 7) * 8 + (lane >> 3);
-        const int sc = (lane & 7) ^ ((row >> 1) & 7);                     // source chunk of physical chunk lane&7 (att_off<8>)
+        const int sc = src_chunk(row);
         d_off[q] = k_wave ? (unsigned)(row * p.ldk + sc * 8) * (unsigned)sizeof(T) : (unsigned)(row * p.ldvt + sc * 8) * (unsigned)sizeof(T);
     }
     auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
             for (int q = 0; q < PPW; ++q) {
                 const int pc = wave_u * PPW + q;
                 const int row = (pc & 7) * 8 + (lane >> 3);
-                const int sc = (lane & 7) ^ ((row >> 1) & 7);
+                const int sc = src_chunk(row);
                 if (k_wave) {                                             // rows past tk: the last key again (masked below)
                     const int key = kv0 + row < p.tk ? kv0 + row : p.tk - 1;
                     glds16_sv(kp, (unsigned)(key * p.ldk + sc * 8) * (unsigned)sizeof(T), dst + pc * 1024);
@@ -268,14 +294,22 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
         }
     };
 
-    // Q^T fragments (B operand of S^T = K Q^T): query q0 + 16*qf + lr, chunk kg*4 + lq
+    // Q^T fragments (B operand of S^T = K Q^T): query q0 + 16*qf + lr, chunk kg*4 + lq, in log2 score units
+    const float c2 = p.scale * 1.44269504088896341f;
+    const bool q_ready = fabsf(c2 - 1.0f) < 1e-6f;           // (uniform) the caller's q already carries scale * log2(e)
     chunk_t qfr[QF][2];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         const int qi = q0 + f * 16 + lr;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-            qfr[f][kg] = (qi < p.tq) ? *(const chunk_t*)(qp + (int64_t)qi * p.ldq + (kg * 4 + lq) * 8) : zero_chunk<T>();
+        for (int kg = 0; kg < 2; ++kg) {
+            chunk_t x = (qi < p.tq) ? *(const chunk_t*)(qp + (int64_t)qi * p.ldq + (kg * 4 + lq) * 8) : zero_chunk<T>();
+            if (!q_ready) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (T)((float)x[j] * c2);
+            }
+            qfr[f][kg] = x;
+        }
     }
     // the compiler must see the Q loads retired BEFORE the tile loop: otherwise (it cannot see the hand-written counted
     // waits) it drains vmcnt to 0 at their first use INSIDE the loop, every tile, and the DMA ring never overlaps
@@ -283,15 +317,19 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) reg_fence(qfr[f][kg]);
-    f32x4 oacc[QF][4];
+    chunk_t ones;
 #pragma unroll
-    for (int f = 0; f < QF; ++f)
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+    f32x4 oacc[QF][4], lacc[QF], negm[QF];
+    float m_ref[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[QF], l_run[QF];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) { m_run[f] = -1e30f; l_run[f] = 0.f; }
-    const float c2 = p.scale * 1.44269504088896341f;       // scores in log2 units: p = 2^(s*c2 - m)
+        lacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negm[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_ref[f] = 0.f;
+    }
 
     dma_tile(0, 0);
     if (ntile > 1) dma_tile(1, 1);
@@ -311,88 +349,91 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
             }
             lds_barrier();
         }
-        // ---- S^T = K Q^T : sacc[f][kf][r] = S[query q0+16f+lr][key kv0 + 16kf + 4lq + r] ----
+        // ---- S^T = K Q^T - m_ref : sacc[f][kf][r] = log2-score of (query q0+16f+lr, key kv0 + att_key_of(kf, 4lq + r)) relative to
+        // the query's reference ----
         f32x4 sacc[QF][4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             chunk_t ka[2];
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg) ka[kg] = *(const chunk_t*)(Ks + att_off<8>(kf * 16 + lr, kg * 4 + lq));
+            for (int kg = 0; kg < 2; ++kg) ka[kg] = *(const chunk_t*)(Ks + att_koff(att_key_of(kf, lr), kg * 4 + lq));
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 a = negm[f];
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg) a = mma_chunk(ka[kg], qfr[f][kg], a);
                 sacc[f][kf] = a;
             }
         }
-        // ---- online softmax, lane-local per query apart from two xor-shuffles for the max.  The softmax is the VALU
-        // bound of this kernel (d = 64: 32 v_exp per 32 MFMAs), so: the running max is kept in RAW score units (scale > 0:
-        // same argmax), scale*log2(e) is folded into one FMA per probability, and the key masks (key tail, causal) are
-        // only evaluated on the tiles that can be masked at all ----
-        const bool need_mask = (kv0 + BKV > p.tk) || (p.causal && kv0 + BKV - 1 > q0);
-        auto softmax = [&](auto maskc) __attribute__((always_inline)) {
-            constexpr bool MASK = decltype(maskc)::value;
+        // the key masks (key tail, causal) are only evaluated on the tiles that can be masked at all
+        if ((kv0 + BKV > p.tk) || (p.causal && kv0 + BKV - 1 > q0)) {
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + att_key_of(kf, lq * 4 + r);
+                        if (key >= p.tk || (p.causal && key > q0 + f * 16 + lr)) sacc[f][kf][r] = -1e30f;
+                    }
+        }
+        float mt[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            mt[f] = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mt[f] = fmaxf(mt[f], sacc[f][kf][r]);
+        }
+        // ---- slow path (first tile; some score more than 2^LAZY above its reference): move the references ----
+        if (t == 0 || wave_any(fmaxf(mt[0], mt[1]) > LAZY)) {
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                float mt = -1e30f;
+                const float m = quad_max(mt[f]);
+                const float m_new = m_ref[f] + (t == 0 ? m : fmaxf(m, 0.f));
+                const float dd = m_new - m_ref[f];
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (MASK) {
-                            const int key = kv0 + kf * 16 + lq * 4 + r;
-                            if (key >= p.tk || (p.causal && key > q0 + f * 16 + lr)) sacc[f][kf][r] = -1e30f;
-                        }
-                        mt = fmaxf(mt, sacc[f][kf][r]);
-                    }
-                mt = quad_max(mt);
-                const float m_new = fmaxf(m_run[f], mt);
-                const float alpha = exp2_fast((m_run[f] - m_new) * c2);
-                const float mc = m_new * c2;
-                float psum = 0.f;
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = exp2_fast(__builtin_fmaf(sacc[f][kf][r], c2, -mc));
-                        sacc[f][kf][r] = pv;
-                        psum += pv;
-                    }
-                l_run[f] = l_run[f] * alpha + psum;             // per-lane partial; quads are summed once at the end
-                if (wave_any(m_new != m_run[f])) {              // wave-uniform: rescale only when some running max moved
+                    for (int r = 0; r < 4; ++r) sacc[f][kf][r] -= dd;
+                if (t > 0) {
+                    const float alpha = exp2_fast(-dd);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
+                    lacc[f] *= alpha;
                 }
-                m_run[f] = m_new;
+                m_ref[f] = m_new;
+                negm[f] = f32x4{-m_new, -m_new, -m_new, -m_new};
             }
-        };
-        if (need_mask) softmax(std::true_type{});
-        else softmax(std::false_type{});
-        // ---- O^T += V^T P^T : keys 32g + 4lq..+3 and 32g + 16 + 4lq..+3 of V^T row 16i + lr ----
+        }
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[f][kf][r] = exp2_fast(sacc[f][kf][r]);
+        // ---- O^T += V^T P^T, row sums += 1 P^T : the lane's 8 probabilities of group g are keys kv0 + 32g + 8lq .. +7 ----
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             chunk_t pb[QF];
 #pragma unroll
-            for (int f = 0; f < QF; ++f) pb[f] = pack_p(sacc[f][2 * g], sacc[f][2 * g + 1], T());
+            for (int f = 0; f < QF; ++f) {
+                pb[f] = pack_p(sacc[f][2 * g], sacc[f][2 * g + 1], T());
+                lacc[f] = mma_chunk(ones, pb[f], lacc[f]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = i * 16 + lr;
-                union { chunk_t c; uint64_t u[2]; } a;
-                a.u[0] = *(const uint64_t*)(Vs + att_off<8>(row, g * 4 + (lq >> 1)) + (lq & 1) * 8);
-                a.u[1] = *(const uint64_t*)(Vs + att_off<8>(row, g * 4 + 2 + (lq >> 1)) + (lq & 1) * 8);
+                const chunk_t a = *(const chunk_t*)(Vs + att_off<8>(i * 16 + lr, g * 4 + lq));
 #pragma unroll
-                for (int f = 0; f < QF; ++f) oacc[f][i] = mma_chunk(a.c, pb[f], oacc[f][i]);
+                for (int f = 0; f < QF; ++f) oacc[f][i] = mma_chunk(a, pb[f], oacc[f][i]);
             }
         }
     }
-    // ---- finalize: sum the per-quad partial row sums, normalise, store 4 consecutive d per lane ----
+    // ---- finalize: every lane holds the row sum of its query; normalise, store 4 consecutive d per lane ----
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        float l_tot = l_run[f];
-        l_tot += __shfl_xor(l_tot, 16);
-        l_tot += __shfl_xor(l_tot, 32);
-        const float inv = 1.0f / l_tot;
+        const float inv = 1.0f / lacc[f][0];
         const int qi = q0 + f * 16 + lr;
         if (qi < p.tq) {
             T* op = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D;

@@ -19,8 +19,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 # "<file>" or "<file>#<n>": conv3x3_w32.hip is compiled as four translation units, one (dtype, tile) family of instantiations each
 # (-DW32_PART=n; the whole file in one unit is 4 minutes of hipcc), in parallel with everything else
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip",
-           "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "calib.hip", "plan_file.hip", "runtime_hip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip#0", "gemm_w32.hip#1",
+           "conv_narrow.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "calib.hip", "plan_file.hip", "runtime_hip.hip"]
 
 
 def _split(src):

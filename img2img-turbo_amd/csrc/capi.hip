@@ -42,7 +42,6 @@ int dispatch(const i2i_op& op, void* stream) {
         case I2I_OP_EMBED: return i2i_embed(&op.u.embed, op.dtype, stream);
         case I2I_OP_LORA_MERGE: return i2i_lora_merge(&op.u.lora_merge, op.dtype, stream);
         case I2I_OP_RESIZE_U8: return i2i_resize_u8(&op.u.resize_u8, op.dtype, stream);
-        case I2I_OP_GN_NORM: return i2i_gn_norm(&op.u.gn_norm, op.dtype, stream);
         case I2I_OP_NOP: return i2i_nop(stream);
         default: return i2i::fail(I2I_ERR_BAD_ARG, "run: unknown opcode %d", op.opcode);
     }

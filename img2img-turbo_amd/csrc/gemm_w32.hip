@@ -843,7 +843,16 @@ int launch_g32_t(const i2i_igemm_params& p, hipStream_t s) {
 
 }  // namespace
 
+// ---- Two translation units (W32_PART = 0 / 1, csrc/build.py and tests/emu/build_emu.py; without it: everything): one per 16-bit type, so
+// that the ~80 instantiations compile side by side.  Part 0 also holds the eligibility rules and the dispatcher.
+#if !defined(W32_PART) || W32_PART == 1
 namespace i2i {
+int gemm_w32_f16(const i2i_igemm_params& p, hipStream_t s) { return launch_g32_t<_Float16>(p, s); }
+}  // namespace i2i
+#endif
+#if !defined(W32_PART) || W32_PART == 0
+namespace i2i {
+int gemm_w32_f16(const i2i_igemm_params& p, hipStream_t s);
 // GroupNorm partial-sum slots per image the wide GEMM writes for this op (0 = it cannot): the 128-column tiles (53 / 54), row
 // tiles that do not straddle images, channels-per-group a multiple of 4 that divides the 128 columns of a tile.
 static int g32_gn_parts(const i2i_igemm_params& p, int groups) {
@@ -917,8 +926,9 @@ bool gemm_w32_auto(const i2i_igemm_params& p, int dtype) {
 int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     switch (dtype) {
         case I2I_BF16: return launch_g32_t<__bf16>(p, s);
-        case I2I_F16: return launch_g32_t<_Float16>(p, s);
+        case I2I_F16: return gemm_w32_f16(p, s);
     }
     return fail(I2I_ERR_BAD_ARG, "gemm_w32: bad dtype");
 }
 }  // namespace i2i
+#endif  // W32_PART == 0

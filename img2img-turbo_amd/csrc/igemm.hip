@@ -34,6 +34,10 @@ bool gemm_w32_eligible(const i2i_igemm_params& p, int dtype);       // gemm_w32.
 bool gemm_w32_auto(const i2i_igemm_params& p, int dtype);           // tile == 0: does the wide GEMM take this op?
 int gemm_w32_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 int gemm_w32(const i2i_igemm_params& p, int dtype, hipStream_t s);
+bool conv_narrow_eligible(const i2i_igemm_params& p, int dtype);    // conv_narrow.hip (tile ids 60..69)
+bool conv_narrow_auto(const i2i_igemm_params& p, int dtype);
+int conv_narrow_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
+int conv_narrow(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
 
 namespace {
@@ -335,6 +339,9 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
+    // the narrow-input 3x3 conv (VAE conv_in: 8 padded input channels; conv_narrow.hip; tile 0 = auto, 60..69 = force)
+    if (p.tile >= 60 && p.tile <= 69 && !i2i::conv_narrow_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (narrow-input conv) not applicable", p.tile);
+    if ((p.tile >= 60 && p.tile <= 69) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return i2i::conv_narrow(p, dtype, s);
     // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..56 = force)
     if (p.tile >= 57 && p.tile <= 59) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d is not a wide-GEMM configuration (50 = auto, 51..56)", p.tile);
     if (p.tile >= 50 && p.tile <= 56 && !i2i::gemm_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (wide GEMM) not applicable", p.tile);
@@ -360,6 +367,7 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32_gn_parts(p, dtype, groups);
     const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
+    if ((p.tile >= 60 && p.tile <= 69) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return i2i::conv_narrow_gn_parts(p, dtype, groups);
     if (routes_to_gemm_w32(p, dtype)) return i2i::gemm_w32_gn_parts(p, dtype, groups);      // (0 for the 160-column tiles: a planner may force tile 20 instead)
     if (p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) return i2i::igemm_dma_gn_parts(p, dtype, groups);
     return 0;
@@ -373,6 +381,7 @@ extern "C" const char* i2i_igemm_route(const i2i_igemm_params* pp, int dtype) {
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return p.subpix ? "conv3x3_w32_kernel<SUBPIX>" : "conv3x3_w32_kernel";
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return p.subpix ? "conv3x3_halo_kernel<SUBPIX>" : "conv3x3_halo_kernel";
+    if ((p.tile >= 60 && p.tile <= 69 && i2i::conv_narrow_eligible(p, dtype)) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return "conv_narrow_kernel";
     if (routes_to_gemm_w32(p, dtype)) return "gemm_w32_kernel";
     if ((p.tile == 0 || (p.tile >= 20 && p.tile <= 29)) && i2i::igemm_dma_eligible(p, dtype)) return "igemm_dma_kernel";
     return "igemm_kernel";

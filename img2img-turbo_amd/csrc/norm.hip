@@ -556,170 +556,12 @@ __global__ __launch_bounds__(256) void gn_stats_sliced_kernel(const i2i_gn_stats
 }
 
 
-// ---- GroupNorm statistics AND apply as ONE op of two lean launches (i2i_gn_norm_params; the consumers that stage their operand by LDS-DMA
-// read the normalised tensor from HBM anyway: the UNet's 3x3 convolutions and proj_in on the wide GEMM).  The gn_stats + gn_apply (x2 for
-// a concat) chain was 2-3 launches, the statistics launch ending in a ticket + last-arriver tail.  Here workgroup (slice, image) of launch 1
-// reduces its pixels to per-group SHIFTED sums sum(x - K_g), sum((x - K_g)^2), K_g = the group's first channel at pixel 0 of the image
-// (every slice reads the same pivot; E[d^2] - E[d]^2 then has nothing to cancel, whatever DC offset the tensor sits on: no second pass),
-// stores them and is done; every workgroup of launch 2 sums all slices' pairs of its image in a fixed order (same bits everywhere),
-// builds (scale, shift) of every channel in LDS and normalises its own pixels of BOTH concat sources into one tensor.
-// Round 6 measured the single-launch form first -- the slices of an image meeting at an arrive counter inside the launch (agent-scope
-// publish, ticket, bounded poll, sc1 fetch): correct on hardware, and 15-18 us per launch even on the smallest tensor (five serial
-// fabric round trips: store ack, ticket, poll, fetch, depart), +0.43 ms per step at batch 8 and +0.8 ms at batch 1 against the launches it
-// replaced (profiles/r6b_ab_*.log; MI355X_MICROARCH.md prices a 256-workgroup barrier at >= 7.4 us).  The launch boundary is the cheaper
-// barrier on this chip.
-constexpr int GNN_ROUNDS = 2;      // 8-channel units per thread: 2 * 256 * 8 = 4096 channels
-
-template <typename T>
-__global__ __launch_bounds__(256) void gn_norm_kernel(const i2i_gn_norm_params p, int phase) {
-    typedef typename Elem<T>::chunk_t chunk_t;
-    constexpr int EPC = Elem<T>::EPC, H = 8 / EPC;
-    const int tid = threadIdx.x, sl = blockIdx.x, img = blockIdx.y, S = p.nslices;
-    const int ct = p.c0 + p.c1, cc = ct >> 3, cpg = ct / p.groups, G = p.groups;
-    const int per = (p.hw + S - 1) / S, px_lo = sl * per, px_hi = px_lo + per < p.hw ? px_lo + per : p.hw;
-    float* red = (float*)i2i_smem;                // [256][16]
-    float* chs = red + 256 * 16;                  // [ct][2] shifted (sum, sum of squares) of the slice per channel
-    float* piv = chs + 2 * ct;                    // [G]
-    float* gst = piv + G;                         // [G][2] mean, rstd
-    float* ssl = gst + 2 * G;                     // [ct][2] scale, shift
-    const T* x0 = (const T*)p.x0 + (int64_t)img * p.hw * p.ld0;
-    const T* x1 = p.x1 ? (const T*)p.x1 + (int64_t)img * p.hw * p.ld1 : nullptr;
-    // thread <-> (unit of a round, pixel row): UR units side by side (one pixel's channels: coalesced), ppb pixels per sweep
-    const int UR = cc < 256 ? cc : 256, ppb = 256 / UR, nrounds = (cc + 255) / 256;
-    const int uir = tid % UR, prow = tid / UR;
-    for (int g = tid; g < G; g += 256) {
-        const int c = g * cpg;
-        piv[g] = to_f32<T>(c < p.c0 ? x0[c] : x1[c - p.c0]);
-    }
-    __syncthreads();
-    float* slot = p.partial + ((int64_t)img * S + sl) * G * 2;
-    if (phase == 1) {
-        for (int rd = 0; rd < nrounds; ++rd) {
-            const int unit = rd * 256 + uir, c = unit * 8;
-            float s[8], q[8], kv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; kv[e] = 0.f; }
-            if (unit < cc && prow < ppb) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kv[e] = piv[(c + e) / cpg];
-                const T* src = (c < p.c0) ? x0 + c : x1 + (c - p.c0);
-                const int ld = (c < p.c0) ? p.ld0 : p.ld1;
-                constexpr int UNR = 4;
-                for (int px0 = px_lo + prow; px0 < px_hi; px0 += ppb * UNR) {
-                    chunk_t v[UNR][H];
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const int px = px0 + u * ppb;
-#pragma unroll
-                        for (int h = 0; h < H; ++h) v[u][h] = *(const chunk_t*)(src + (int64_t)(px < px_hi ? px : px0) * ld + h * EPC);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u)
-                        if (px0 + u * ppb < px_hi) {
-#pragma unroll
-                            for (int h = 0; h < H; ++h)
-#pragma unroll
-                                for (int e = 0; e < EPC; ++e) {
-                                    const float d = to_f32<T>(v[u][h][e]) - kv[h * EPC + e];
-                                    s[h * EPC + e] += d;
-                                    q[h * EPC + e] += d * d;
-                                }
-                        }
-                }
-            }
-            __syncthreads();                      // (the previous round's readers of `red` are done)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = q[e]; }
-            __syncthreads();
-            for (int k = tid; k < UR * 8; k += 256) {      // per-channel totals over the pixel rows, fixed order
-                const int u = k >> 3, e = k & 7, cch = (rd * 256 + u) * 8 + e;
-                if (rd * 256 + u < cc) {
-                    float S1 = 0.f, Q1 = 0.f;
-                    for (int r = 0; r < ppb; ++r) { S1 += red[(r * UR + u) * 16 + e]; Q1 += red[(r * UR + u) * 16 + 8 + e]; }
-                    chs[2 * cch] = S1; chs[2 * cch + 1] = Q1;
-                }
-            }
-        }
-        __syncthreads();
-        for (int g = tid; g < G; g += 256) {
-            float S1 = 0.f, Q1 = 0.f;
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S1 += chs[2 * c]; Q1 += chs[2 * c + 1]; }
-            slot[g * 2] = S1;
-            slot[g * 2 + 1] = Q1;
-        }
-        return;
-    }
-    // ---- every slice of the image has published: all pairs, summed in slice order (nsl lanes of slices, then the lanes in order)
-    {
-        const int nsl = 256 / G > 0 ? 256 / G : 1;
-        const int g = tid % G, j = tid / G;
-        float S1 = 0.f, Q1 = 0.f;
-        if (tid < nsl * G) {
-            const float* base = p.partial + (int64_t)img * S * G * 2;
-            for (int k = j; k < S; k += nsl) {
-                S1 += base[((int64_t)k * G + g) * 2];
-                Q1 += base[((int64_t)k * G + g) * 2 + 1];
-            }
-        }
-        __syncthreads();
-        red[2 * tid] = S1; red[2 * tid + 1] = Q1;
-        __syncthreads();
-        for (int gg = tid; gg < G; gg += 256) {
-            float A = 0.f, B = 0.f;
-            for (int k = 0; k < nsl; ++k) { A += red[(k * G + gg) * 2]; B += red[(k * G + gg) * 2 + 1]; }
-            const float inv = 1.0f / ((float)cpg * (float)p.hw), m1 = A * inv;
-            gst[2 * gg] = piv[gg] + m1;
-            gst[2 * gg + 1] = rsqrtf(fmaxf(B * inv - m1 * m1, 0.f) + p.eps);
-        }
-        __syncthreads();
-        for (int c = tid; c < ct; c += 256) {
-            const int gg = c / cpg;
-            const float sc = gst[2 * gg + 1] * p.gamma[c];
-            ssl[2 * c] = sc;
-            ssl[2 * c + 1] = p.beta[c] - gst[2 * gg] * sc;
-        }
-        __syncthreads();
-    }
-    // ---- apply to the slice's own pixels (the second read comes out of the L2 / MALL)
-    T* y = (T*)p.y + (int64_t)img * p.hw * p.ldy;
-    for (int rd = 0; rd < nrounds; ++rd) {
-        const int unit = rd * 256 + uir, c = unit * 8;
-        if (unit < cc && prow < ppb) {
-            float sc[8], sh[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = ssl[2 * (c + e)]; sh[e] = ssl[2 * (c + e) + 1]; }
-            const T* src = (c < p.c0) ? x0 + c : x1 + (c - p.c0);
-            const int ld = (c < p.c0) ? p.ld0 : p.ld1;
-            constexpr int UNR = 4;
-            for (int px0 = px_lo + prow; px0 < px_hi; px0 += ppb * UNR) {
-                chunk_t v[UNR][H];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int px = px0 + u * ppb;
-#pragma unroll
-                    for (int h = 0; h < H; ++h) v[u][h] = *(const chunk_t*)(src + (int64_t)(px < px_hi ? px : px0) * ld + h * EPC);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int px = px0 + u * ppb;
-                    if (px < px_hi) {
-#pragma unroll
-                        for (int h = 0; h < H; ++h) {
-                            chunk_t o;
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) {
-                                float f = to_f32<T>(v[u][h][e]) * sc[h * EPC + e] + sh[h * EPC + e];
-                                if (p.act == 1) f = silu_f(f);
-                                o[e] = from_f32<T>(f);
-                            }
-                            *(chunk_t*)(y + (int64_t)px * p.ldy + c + h * EPC) = o;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
+// (Round 6, measured negative, removed: GroupNorm statistics + apply as ONE op for the consumers that read a materialised operand.  First
+// as a single launch -- the pixel slices of an image meeting at an arrive counter inside the launch, agent-scope publish / ticket / bounded
+// poll / sc1 fetch: correct on hardware, 15-18 us per launch even on the smallest tensor (five serial fabric round trips), +0.43 ms per
+// step at batch 8 and +0.81 ms at batch 1 against the gn_stats + gn_apply launches it replaced; then as two lean launches (slice sums
+// with a pivot shift, finalize-and-apply): +0.11 ms at batch 8, +0.45 ms at batch 1.  profiles/r6b_ab_*, r6c_ab_*.  The sliced statistics
+// kernel above already spreads a small tensor over ~1000 workgroups; its ticket tail costs less than a second prologue in the apply.)
 
 // Row softmax with the row held in registers (cols <= 4096, multiple of 4, 16-byte aligned rows): one read of the
 // fp32 scores as float4, one write of the probabilities as 4-element vectors.  The generic kernel above makes three
@@ -846,42 +688,6 @@ extern "C" int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* strea
     return i2i::check_launch("gn_apply");
 }
 
-
-// Pixel slices per image of i2i_gn_norm: about 512 workgroups per launch, at least 16 KiB of tensor per slice (a slice re-reads its
-// pixels in the second launch: out of the L2), at most 64 slices per image (the second launch sums every slice's pairs per workgroup).
-extern "C" int i2i_gn_norm_slices(int nimg, int hw, int channels) {
-    if (nimg < 1 || hw < 1 || channels < 1) return 1;
-    int s = 512 / nimg;
-    const int by_bytes = (int)(((int64_t)hw * channels * 2) / 16384);
-    if (s > by_bytes) s = by_bytes;
-    if (s > hw) s = hw;
-    if (s > 64) s = 64;
-    return s < 1 ? 1 : s;
-}
-
-extern "C" int i2i_gn_norm(const i2i_gn_norm_params* p, int dtype, void* stream) {
-    if (!p || !p->x0 || !p->y || !p->gamma || !p->beta || !p->partial) return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: null pointer");
-    const int ct = p->c0 + p->c1;
-    if (p->c0 % 8 || p->c1 % 8 || p->ld0 % 8 || (p->x1 && p->ld1 % 8) || p->ldy % 8 || p->ldy < ct) return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: channels / strides must be multiples of 8");
-    if ((p->c1 != 0) != (p->x1 != nullptr)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: x1/c1 mismatch");
-    if (p->groups < 1 || p->groups > 256 || ct % p->groups || ct > GNN_ROUNDS * 256 * 8 || p->nimg < 1 || p->hw < 1)
-        return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: bad geometry (ct=%d groups=%d)", ct, p->groups);
-    if (((uintptr_t)p->x0 | (uintptr_t)p->x1 | (uintptr_t)p->y) & 15) return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: tensors must be 16-byte aligned");
-    const int S = p->nslices;
-    if (S < 1 || S > p->hw || S > 4096) return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: bad slice count %d", S);
-    const size_t smem = (size_t)(256 * 16 + 4 * ct + 3 * p->groups + 4) * sizeof(float);
-    const dim3 grid((unsigned)S, (unsigned)p->nimg);
-    hipStream_t s = (hipStream_t)stream;
-    for (int ph = 1; ph <= 2; ++ph) {
-        switch (dtype) {
-            case I2I_F32: hipLaunchKernelGGL((gn_norm_kernel<float>), grid, dim3(256), smem, s, *p, ph); break;
-            case I2I_BF16: hipLaunchKernelGGL((gn_norm_kernel<__bf16>), grid, dim3(256), smem, s, *p, ph); break;
-            case I2I_F16: hipLaunchKernelGGL((gn_norm_kernel<_Float16>), grid, dim3(256), smem, s, *p, ph); break;
-            default: return i2i::fail(I2I_ERR_BAD_ARG, "gn_norm: bad dtype");
-        }
-    }
-    return i2i::check_launch("gn_norm");
-}
 
 extern "C" int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream) {
     if (!p || !p->x || !p->y || !p->gamma || !p->beta) return i2i::fail(I2I_ERR_BAD_ARG, "layernorm: null pointer");

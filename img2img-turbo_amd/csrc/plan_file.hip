@@ -79,7 +79,6 @@ const std::vector<size_t>& ptr_fields(int opcode) {
     static const std::vector<size_t> lora = {PF(lora_merge, dst), PF(lora_merge, w0), PF(lora_merge, a), PF(lora_merge, b), PF(lora_merge, rg),
                                              PF(lora_merge, kscale), PF(lora_merge, kshift), PF(lora_merge, bias0), PF(lora_merge, colsum), PF(lora_merge, bias_out)};
     static const std::vector<size_t> resize = {PF(resize_u8, src), PF(resize_u8, dst), PF(resize_u8, bounds), PF(resize_u8, coeffs)};
-    static const std::vector<size_t> gn_norm = {PF(gn_norm, x0), PF(gn_norm, x1), PF(gn_norm, gamma), PF(gn_norm, beta), PF(gn_norm, y), PF(gn_norm, partial)};
     switch (opcode) {
         case I2I_OP_IGEMM: return igemm;
         case I2I_OP_GN_STATS: return gn_stats;
@@ -94,7 +93,6 @@ const std::vector<size_t>& ptr_fields(int opcode) {
         case I2I_OP_EMBED: return embed;
         case I2I_OP_LORA_MERGE: return lora;
         case I2I_OP_RESIZE_U8: return resize;
-        case I2I_OP_GN_NORM: return gn_norm;
         default: return none;
     }
 }

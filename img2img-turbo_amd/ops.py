@@ -93,21 +93,6 @@ def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=
     return K.OP_GN_STATS, _keep(p, x0, x1, gamma, beta, partial, ss, counters)
 
 
-def gn_norm(x0, y, gamma, beta, partial, *, nimg, hw, groups, eps, act, nslices, x1=None, c0=None, c1=0, ld0=None, ld1=None, ldy=None):
-    """y = act(group_norm(cat(x0, x1))) as one op (slice statistics launch + finalize-and-apply launch): i2i_gn_norm_params."""
-    p = K.GnNormParams()
-    p.x0, p.x1 = ptr(x0), ptr(x1)
-    p.c0 = x0.shape[-1] if c0 is None else c0
-    p.c1 = c1
-    p.ld0 = ld0 if ld0 is not None else p.c0
-    p.ld1 = (ld1 if ld1 is not None else c1) if x1 is not None else 0
-    p.nimg, p.hw, p.groups, p.eps = nimg, hw, groups, eps
-    p.gamma, p.beta = ptr(gamma), ptr(beta)
-    p.y, p.ldy, p.act = ptr(y), (ldy if ldy is not None else p.c0 + c1), act
-    p.partial, p.nslices = ptr(partial), nslices
-    return K.OP_GN_NORM, _keep(p, x0, x1, y, gamma, beta, partial)
-
-
 def gn_apply(x, y, ss, *, nimg, hw, c, act, ldx=0, ldy=0, ss_ld=0, ss_off=0, y_off=0):
     """y[..., y_off:y_off+c] = act(x * scale + shift); ``y_off``/``ldy`` write a channel slice of a wider buffer."""
     p = K.GnApplyParams()

@@ -105,6 +105,8 @@ class Packer:
 
     def _up(self, t, dtype=None):
         t = t.to(dtype or self.dtype).contiguous().to(self.device)
+        if t.data_ptr() % 16:      # (CPU device only: a memory-mapped safetensors view is 8-byte aligned; the kernels read 16-byte vectors)
+            t = t.clone()
         self.nbytes += t.numel() * t.element_size()
         return t
 
@@ -177,13 +179,23 @@ class Packer:
         return torch.cat(outs, dim=-1).reshape(o, -1)
 
     # ------------------------------------------------------------------ packed layers
-    def conv(self, name, split=None, extra_bias=None, gamma=False):
+    @staticmethod
+    def _scaled(w, b, ab, c):
+        """The layer whose output is ``c`` times the layer's: rows of W, the bias and the rows of lora_B scaled (fp32, before any
+        rounding: the packed weights are rounded once either way)."""
+        if c is None:
+            return w, b, ab
+        return w * c, (None if b is None else b * c), (None if ab is None else (ab[0], ab[1] * c))
+
+    def conv(self, name, split=None, extra_bias=None, gamma=False, out_scale=None):
         """-> dict(w=[N][K] dtype, b=fp32 or None, n=N, ks=k).  ``split``: channel count of concat source 0;
-        ``gamma``: the skip-conv weights carry the decoder's skip gamma (src/model.py:41-43)."""
-        key = ("conv", name, split, bool(gamma), extra_bias is not None)     # a second call with other flags must not get the first packing
+        ``gamma``: the skip-conv weights carry the decoder's skip gamma (src/model.py:41-43); ``out_scale``: a constant factor on
+        the layer's output folded into W, bias and lora_B (attention: to_q carries scale * log2(e), plan.attention_block)."""
+        key = ("conv", name, split, bool(gamma), extra_bias is not None, out_scale)     # a second call with other flags must not get the first packing
         if key not in self.cache:
             w, b = self.base(name)
             ab = self.lora(name)
+            w, b, ab = self._scaled(w, b, ab, out_scale)
             if extra_bias is not None:
                 b = extra_bias if b is None else b + extra_bias
             if w.dim() == 2:
@@ -247,11 +259,14 @@ class Packer:
             self.cache[key] = ent
         return self.cache[key]
 
-    def stacked_linear(self, names):
-        """Rows of several linears stacked (q|k projections share one GEMM)."""
-        key = ("stack",) + tuple(names)
+    def stacked_linear(self, names, scale0=None):
+        """Rows of several linears stacked (q|k projections share one GEMM).  ``scale0``: output factor of the FIRST layer (see conv)."""
+        key = ("stack", scale0) + tuple(names)
         if key not in self.cache:
-            parts = [(self.base(n), self.lora(n)) for n in names]
+            parts = []
+            for i, n in enumerate(names):
+                w, b, ab = self._scaled(*self.base(n), self.lora(n), scale0 if i == 0 else None)
+                parts.append(((w, b), ab))
             rows = sum(p[0][0].shape[0] for p in parts)
             k = parts[0][0][0].shape[1]
             dst = torch.empty(rows, k, dtype=self.dtype, device=self.device)
@@ -265,15 +280,19 @@ class Packer:
             self.cache[key] = dict(w=dst, b=None if b is None else self._up(b, torch.float32), n=rows, ks=1)
         return self.cache[key]
 
-    def ln_linear(self, names, norm_name, geglu=False):
+    def ln_linear(self, names, norm_name, geglu=False, scale0=None):
         """Linear layer(s) with the LayerNorm in front of them folded in (diffusers BasicTransformerBlock: norm1 -> attn1.to_q / to_k /
         to_v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj): rows of ``names`` stacked (GEGLU rows interleaved per 16 as geglu_linear),
         W' = W * gamma[k] written by the device-side merge together with the two per-row vectors the consumer GEMM needs
-        (i2i_igemm_params.ln_cs): -> dict(w, b = bias' = bias + W.beta, cs = row sums of the stored W', n, ks=1)."""
-        key = ("ln", norm_name, bool(geglu)) + tuple(names)
+        (i2i_igemm_params.ln_cs): -> dict(w, b = bias' = bias + W.beta, cs = row sums of the stored W', n, ks=1).  ``scale0``: output factor
+        of the FIRST layer (see conv)."""
+        key = ("ln", norm_name, bool(geglu), scale0) + tuple(names)
         if key not in self.cache:
             gamma, beta = self.norm(norm_name)
-            parts = [(self.base(n), self.lora(n)) for n in names]
+            parts = []
+            for i, n in enumerate(names):
+                w, b, ab = self._scaled(*self.base(n), self.lora(n), scale0 if i == 0 else None)
+                parts.append(((w, b), ab))
             rows = sum(p[0][0].shape[0] for p in parts)
             k = parts[0][0][0].shape[1]
             assert gamma.numel() == k, (norm_name, gamma.shape, k)

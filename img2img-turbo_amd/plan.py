@@ -131,14 +131,12 @@ class ForwardPlan:
         self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
         self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
+        self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
         # round 6: LayerNorm folded into the GEMM behind it (norm1 -> to_q | to_k | to_v^T in ONE launch, norm2 -> to_q, norm3 -> GEGLU on the
-        # small planes: csrc/gemm_w32.hip LNF; 16-bit types) and GroupNorm statistics + apply as one two-launch op for the consumers that
-        # read a materialised operand (csrc/norm.hip gn_norm_kernel).  A/B hooks.
+        # small planes: csrc/gemm_w32.hip LNF; 16-bit types).  A/B hook.
         self.ln_fold = os.environ.get("I2I_LN_FOLD", "1") != "0" and self.unet_dtype != torch.float32
         self.ln_fold_geglu_max_rows = int(os.environ.get("I2I_LN_FOLD_GEGLU_ROWS", "1024"))
-        self.gn_norm_fused = os.environ.get("I2I_GN_NORM", "1") != "0"
-        self._gnn_part_elems = 0
         lat = self.va.latent_channels
         h8, w8 = H // 8, W // 8
         self.out_dtype = out_dtype or dtype
@@ -183,7 +181,7 @@ class ForwardPlan:
         self.op_flops_exec.append(flops if flops_exec is None else flops_exec)
         self.op_bytes.append(nbytes)       # algorithmic HBM bytes of the HBM-bound launches (norms, layout / latent ops); 0 = not priced
         self.op_kernel.append(kernel or {K.OP_GN_STATS: "gn_stats", K.OP_LAYERNORM: "layernorm", K.OP_SOFTMAX: "softmax",
-                                        K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply", K.OP_GN_NORM: "gn_norm",
+                                        K.OP_ATTENTION: "attention_kernel", K.OP_GN_APPLY: "gn_apply",
                                         K.OP_IGEMM: "igemm_dma_kernel"}.get(op[0], "boundary/elementwise"))
 
     def _reroute(self, params, kernel):
@@ -215,12 +213,7 @@ class ForwardPlan:
         # leaves them zero); I2I_GN_SLICED=0 keeps one workgroup per (image, group set) (A/B hook)
         self.gn_counters = torch.zeros(max(self._gn_cnt_elems, 1), dtype=torch.int32, device=self.device)
         sliced = os.environ.get("I2I_GN_SLICED", "1") != "0"
-        # gn_norm (slice statistics + finalize-and-apply): per-slice partial sums.  One slab per plan: the program runs in order on one stream.
-        self.gnn_partial = torch.zeros(max(self._gnn_part_elems, 1), dtype=torch.float32, device=self.device)
         for p, which in self._pending_gn:   # patch pointers now that the scratch exists
-            if which == "norm":
-                p.partial = self.gnn_partial.data_ptr()
-                continue
             if which == "stats":
                 p.partial, p.ss = self.gn_partial.data_ptr(), self.gn_ss.data_ptr()
                 p.counters = self.gn_counters.data_ptr() if sliced else 0
@@ -254,7 +247,7 @@ class ForwardPlan:
                 if x.producer.tile == 0:
                     route = self.lib.igemm_route(x.producer, self.dt)
                     pin = {"conv3x3_w32_kernel": 40, "conv3x3_w32_kernel<SUBPIX>": 40, "conv3x3_halo_kernel": 10,
-                           "conv3x3_halo_kernel<SUBPIX>": 10, "igemm_dma_kernel": 20}.get(route, 0)
+                           "conv3x3_halo_kernel<SUBPIX>": 10, "igemm_dma_kernel": 20, "conv_narrow_kernel": 60}.get(route, 0)
                     if route == "gemm_w32_kernel":      # statistics come from its 128-column tiles only: 256 rows (53) or 128 rows (54)
                         pin = 53 if parts * 256 == x.hw else 54
                     if pin:
@@ -341,9 +334,7 @@ class ForwardPlan:
         ``k2`` = dict(x=Act at output resolution, w=packed 1x1 weights, label, [bias], [fallback]): a second contraction folded
         into this launch when the kernel it routes to takes one (i2i_igemm_params.k2_a); the returned Act then has ``k2_fused``
         set; otherwise ``fallback()`` (if given) records the separate launch and its output becomes this launch's residual."""
-        # gn: False, or (packer, norm name, groups, eps) of the GroupNorm in front of this conv: the statistics launch is recorded HERE,
-        # once the route is known -- gn_stats for the kernels that apply the norm while staging their operand, the one-launch gn_norm
-        # (statistics + apply) for those that read a materialised operand
+        # gn: False, or (packer, norm name, groups, eps) of the GroupNorm in front of this conv: its statistics launch is recorded here
         gn_spec, gn = (gn, True) if isinstance(gn, tuple) else (None, bool(gn))
         ks = ks or pw["ks"]
         pad = (ks // 2 if not asym else 0) if pad is None else pad
@@ -402,29 +393,19 @@ class ForwardPlan:
             if not ok_:
                 halo, force_tile, grp = True, 0, 0
         fused = gn and self.fuse_gn and (halo or not self.dma_small)
-        one_launch_norm = gn and not fused and gn_spec is not None and self.gn_norm_fused and (x.c + c1) <= 4096
-        if gn_spec is not None and not one_launch_norm:
+        if gn_spec is not None:
             self.gn_stats(gn_spec[0], gn_spec[1], x, gn_spec[2], gn_spec[3], x1)
         if gn and not fused:
             # materialise act(GN(x)) (both concat sources into ONE buffer): the LDS-DMA igemm / wide GEMM that take the UNet's
             # planes / 1x1 projections have no operand prologue, and the extra pass is over a few MB at most
             ct = x.c + c1
             y = self.new(x.n, x.h, x.w, ct)
-            if one_launch_norm:
-                gamma, beta = gn_spec[0].norm(gn_spec[1])
-                S = int(self.lib.lib.i2i_gn_norm_slices(x.n, x.hw, ct))
-                self._gnn_part_elems = max(self._gnn_part_elems, x.n * S * gn_spec[2] * 2)
-                op = O.gn_norm(x.t, y.t, gamma, beta, None, nimg=x.n, hw=x.hw, groups=gn_spec[2], eps=gn_spec[3], act=act, nslices=S,
-                               x1=x1.t if x1 else None, c0=x.c, c1=c1, ld0=x.c, ld1=c1, ldy=ct)
-                self._pending_gn.append((op[1], "norm"))
-                self._add(op, label + ".gn_norm", nbytes=2 * x.n * x.hw * ct * self.esz)
-            else:
-                for src, coff in ((x, 0), (x1, x.c)):
-                    if src is None:
-                        continue
-                    op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
-                    self._pending_gn.append((op[1], "apply"))
-                    self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
+            for src, coff in ((x, 0), (x1, x.c)):
+                if src is None:
+                    continue
+                op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+                self._pending_gn.append((op[1], "apply"))
+                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
         mk = lambda tile_, splitk_, ws_: O.conv(
@@ -509,6 +490,8 @@ class ForwardPlan:
         if out is None:
             out = self.pool.get(rows * out_cols, self.dtype)
         splitk, ws = (0, None) if geglu else self._splitk(rows, pw["n"], cin)
+        # (round 6, measured negative: the K-sliced small linears -- a split-K launch + its reduce launch -- as ONE un-sliced wide-GEMM launch
+        # with a handful of tiles: +0.06 ... +0.32 ms at batch 1 for row limits 64 ... 4096, neutral at batch 8; profiles/r6d_ab_bs1_unsplit.log)
         op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
                     res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu, splitk=splitk, ws=ws)
         if ws is not None:
@@ -663,6 +646,12 @@ class ForwardPlan:
         recorded when that launch is not available (the caller runs the LayerNorm and calls again without ``ln``)."""
         d = C // heads
         scale = 1.0 / math.sqrt(d)
+        # the LDS-DMA flash kernel works in log2 units: scale * log2(e) is folded into to_q (W, bias and lora_B in fp32 before the one
+        # rounding of the packed weights), so q leaves its projection ready for v_exp_f32 and the kernel is told scale = ln 2
+        # (softmax(ln2 * (c q).k) with c = scale * log2 e is the same function); csrc/attention.hip attention_dma_kernel
+        qs = None
+        if self.flash and d == 64 and self.dtype != torch.float32 and self.att_q_log2:
+            qs, scale = scale * math.log2(math.e), math.log(2.0)
         vt_fused = None
         if ctx is None:
             tk = T
@@ -671,23 +660,23 @@ class ForwardPlan:
                     return None
                 nt = B * T
                 qk, vt_fused = self.pool.get(B * T * 2 * C, self.dtype), self.pool.get(C * nt, self.dtype)
-                if self.ln_gemm(pk.ln_linear([p + ".to_q", p + ".to_k", p + ".to_v"], ln), xn, B * T, C, out=qk, out_cols=2 * C,
+                if self.ln_gemm(pk.ln_linear([p + ".to_q", p + ".to_k", p + ".to_v"], ln, scale0=qs), xn, B * T, C, out=qk, out_cols=2 * C,
                                 label=p + ".norm+to_qkv^T", n_trans=2 * C, out2=vt_fused, ldc2=nt) is None:
                     self.pool.put(qk)
                     self.pool.put(vt_fused)
                     return None
             else:
-                qk = self.linear(pk.stacked_linear([p + ".to_q", p + ".to_k"]), xn, B * T, C, label=p + ".to_qk")
+                qk = self.linear(pk.stacked_linear([p + ".to_q", p + ".to_k"], scale0=qs), xn, B * T, C, label=p + ".to_qk")
             q, k, ldq, ldk, q_bs, k_bs = qk, qk[C:], 2 * C, 2 * C, T * 2 * C, T * 2 * C
             kv_src, kv_cin, kv_bs = xn, C, T * C
         else:
             cd = self.ua.cross_attention_dim
             if ln is not None:
-                q = self.ln_gemm(pk.ln_linear([p + ".to_q"], ln), xn, B * T, C, label=p + ".norm+to_q")
+                q = self.ln_gemm(pk.ln_linear([p + ".to_q"], ln, scale0=qs), xn, B * T, C, label=p + ".norm+to_q")
                 if q is None:
                     return None
             else:
-                q = self.linear(pk.conv(p + ".to_q"), xn, B * T, C, label=p + ".to_q")
+                q = self.linear(pk.conv(p + ".to_q", out_scale=qs), xn, B * T, C, label=p + ".to_q")
             ldq, q_bs = C, T * C
             qk = None
             merged = self.cross_kv_merged and p.endswith(".attn2")

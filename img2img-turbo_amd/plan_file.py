@@ -55,7 +55,7 @@ def export_plan(plan, path, extra_tensors=()):
         named["noise"] = plan.noise
     # (the GroupNorm scratch -- partial sums, (scale, shift) tables, ticket counters -- is patched into the ops after they were recorded:
     # plan._finish_gn_scratch; produced inside the program, zero at rest)
-    gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters", "gnn_partial")) if t is not None]
+    gn_scratch = [t for t in (getattr(plan, n, None) for n in ("gn_partial", "gn_ss", "gn_counters")) if t is not None]
     return export_program(plan.prog, path, named, scratch=list(plan.pool.all) + gn_scratch, holders=[plan] + list(extra_tensors), device=plan.device)
 
 

@@ -52,8 +52,7 @@ typedef enum {
     I2I_OP_EMBED = 11,
     I2I_OP_LORA_MERGE = 12,
     I2I_OP_RESIZE_U8 = 13,
-    I2I_OP_GN_NORM = 14,
-    I2I_OP_NOP = 15            /* one empty kernel launch (bench.py's calibration: microseconds per hipGraph node) */
+    I2I_OP_NOP = 14            /* one empty kernel launch (bench.py's calibration: microseconds per hipGraph node) */
 } i2i_opcode;
 
 /* ---------------------------------------------------------------------------------------------
@@ -94,7 +93,8 @@ typedef struct {
                                   40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto; with `subpix` its
                                   sub-pixel upsampler form), 50-56 wide GEMM (32x32x16 MFMA, gemm_w32.hip; 50 = its own auto,
                                   51 256x160, 52 128x160, 53 256x128, 54 128x128 workgroup tiles; 55 / 56 = 52 / 54 with a 2-deep
-                                  ring, two workgroups per CU).
+                                  ring, two workgroups per CU); 60-69 the narrow-input 3x3 conv (8 padded input channels into a multiple
+                                  of 128 output channels: the VAE's conv_in; conv_narrow.hip).
                                   `bias` (bias_mode 1) must be 4-byte aligned; the 3x3 conv routes need it 16-byte aligned */
     int32_t splitk;            /* > 1: split the K loop over grid z; needs `ws`; no GEGLU, zcount == 1 */
     void* ws;                  /* fp32 workspace, >= splitk * M * N floats (split-K partial slabs) */
@@ -153,8 +153,7 @@ typedef struct {
                                                  CONCURRENCY: `counters` / `partial` are state of the launch in flight -- an op (and therefore
                                                  a program, a captured graph or a loaded plan file that contains it) must not run on two
                                                  streams at once; consecutive launches on one stream are fine (the kernel leaves the
-                                                 counters at zero).  The same holds for every scratch slab an op names (gn_part, ws,
-                                                 i2i_gn_norm_params.partial). */
+                                                 counters at zero).  The same holds for every scratch slab an op names (gn_part, ws). */
 } i2i_gn_stats_params;
 
 /* Standalone GN apply (+SiLU): y = act(x*scale+shift).  Used where the consumer cannot apply it in its
@@ -263,20 +262,6 @@ typedef struct {
     const int32_t* bounds; const int32_t* coeffs;
 } i2i_resize_u8_params;
 
-/* GroupNorm (+ SiLU) as ONE op: statistics and apply (ABI v9).  y = act(F.group_norm(cat(x0, x1), groups, gamma, beta, eps)) written as one
- * [nimg][hw][ldy] tensor: what the consumers that stage their operand by LDS-DMA read (the UNet's 3x3 convolutions and proj_in on the
- * wide GEMM).  Replaces the I2I_OP_GN_STATS + I2I_OP_GN_APPLY (x2 for a concat) chain by two lean launches: every image is cut into
- * `nslices` pixel slices (i2i_gn_norm_slices()); launch 1 stores each slice's per-group SHIFTED sums (pivot = the group's first channel at
- * pixel 0, so that E[d^2] - E[d]^2 never cancels: no second pass), launch 2 sums them in slice order (deterministic), builds every
- * channel's (scale, shift) and normalises the slice's pixels of both sources.  `partial`: nimg*nslices*groups*2 floats of scratch. */
-typedef struct {
-    const void* x0; const void* x1; int32_t c0, c1, ld0, ld1;
-    int32_t nimg, hw, groups; float eps;
-    const float* gamma; const float* beta;    /* [c0+c1] fp32 */
-    void* y; int32_t ldy; int32_t act;        /* act: 0 none, 1 SiLU */
-    float* partial; int32_t nslices;
-} i2i_gn_norm_params;
-
 typedef struct { int32_t unused; } i2i_nop_params;
 
 typedef struct {
@@ -296,7 +281,6 @@ typedef struct {
         i2i_embed_params embed;
         i2i_lora_merge_params lora_merge;
         i2i_resize_u8_params resize_u8;
-        i2i_gn_norm_params gn_norm;
         i2i_nop_params nop;
     } u;
 } i2i_op;
@@ -313,14 +297,11 @@ int i2i_igemm(const i2i_igemm_params* p, int dtype, void* stream);
  * the kernel that will run it cannot produce GroupNorm partials (planner query; launches nothing). */
 int i2i_igemm_gn_parts(const i2i_igemm_params* p, int dtype, int groups);
 /* Name of the kernel family i2i_igemm() routes this op to ("conv3x3_w32_kernel", "conv3x3_w32_kernel<SUBPIX>",
- * "conv3x3_halo_kernel", "conv3x3_halo_kernel<SUBPIX>", "gemm_w32_kernel", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
+ * "conv3x3_halo_kernel", "conv3x3_halo_kernel<SUBPIX>", "gemm_w32_kernel", "conv_narrow_kernel", "igemm_dma_kernel", "igemm_kernel"): reporting only (bench.py groups its per-op
  * timings by it; the planner does not have to mirror the routing rules).  Launches nothing; never NULL. */
 const char* i2i_igemm_route(const i2i_igemm_params* p, int dtype);
 int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* stream);
 int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream);
-int i2i_gn_norm(const i2i_gn_norm_params* p, int dtype, void* stream);
-/* Pixel slices per image i2i_gn_norm() wants for this shape (planner query: sizes `partial`; launches nothing). */
-int i2i_gn_norm_slices(int nimg, int hw, int channels);
 int i2i_layernorm(const i2i_layernorm_params* p, int dtype, void* stream);
 int i2i_softmax(const i2i_softmax_params* p, int dtype, void* stream);
 int i2i_attention(const i2i_attention_params* p, int dtype, void* stream);

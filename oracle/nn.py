@@ -21,15 +21,32 @@ _LORA_A = re.compile(r"\.lora_A\.([^.]+)\.weight$")
 # fp32 accumulators does at best, so the distance of this run from the plain fp32 oracle is the precision FLOOR of the
 # dtype on a given input; tests/test_e2e_gpu.py holds the HIP path against 1.25 x that floor stage by stage.  Outside the
 # context q() is the identity: the fp32 oracle is untouched.
-_QUANT = {"dtype": None}
+_QUANT = {"dtype": None, "unet": None}
 
 
 class quantized:
-    def __init__(self, dtype):
-        self.dtype, self.prev = dtype, None
+    """``unet_dtype``: another emulated type inside unet_forward (the product's per-network precision: an fp16 UNet beside a bf16 VAE)."""
+
+    def __init__(self, dtype, unet_dtype=None):
+        self.dtype, self.unet_dtype, self.prev = dtype, unet_dtype, None
 
     def __enter__(self):
-        self.prev, _QUANT["dtype"] = _QUANT["dtype"], self.dtype
+        self.prev = dict(_QUANT)
+        _QUANT["dtype"], _QUANT["unet"] = self.dtype, self.unet_dtype
+        return self
+
+    def __exit__(self, *exc):
+        _QUANT.update(self.prev)
+        return False
+
+
+class unet_scope:
+    """Entered by unet_forward: inside, q() rounds to the UNet's emulated type when one was given (identity otherwise)."""
+
+    def __enter__(self):
+        self.prev = _QUANT["dtype"]
+        if _QUANT["unet"] is not None and _QUANT["dtype"] is not None:
+            _QUANT["dtype"] = _QUANT["unet"]
         return self
 
     def __exit__(self, *exc):

@@ -32,6 +32,12 @@ def conv_in(W: Weights, x, twin_r=None):
 
 
 def unet_forward(W: Weights, arch: UNetArch, x, ctx, twin_r=None, t=None):
+    from .nn import unet_scope
+    with unet_scope():
+        return _unet_forward(W, arch, x, ctx, twin_r, t)
+
+
+def _unet_forward(W: Weights, arch: UNetArch, x, ctx, twin_r=None, t=None):
     """x [B,4,h,w], ctx [B,77,cross_dim] -> eps prediction [B,4,h,w]."""
     g, eps = arch.norm_num_groups, arch.norm_eps
     boc, heads = arch.block_out_channels, arch.num_heads

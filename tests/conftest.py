@@ -52,6 +52,18 @@ def gpu_lib():
         torch.set_num_threads(min(nthr, os.cpu_count() or nthr))
     lib = _capi.default_library()
     assert lib.backend == "gfx950"
+    # Parity is "unpinned" (DESIGN.md section 0, row c) only because the reference's dependencies are missing: say on every GPU session
+    # whether this box has them -- the day one does, tests/golden/make_reference_golden.py generates the reference-made fixtures
+    # that tests/test_oracle_kats.py::test_oracle_matches_reference_golden consumes.
+    have = {}
+    for mod in ("diffusers", "peft", "torchvision"):
+        try:
+            __import__(mod)
+            have[mod] = True
+        except Exception:
+            have[mod] = False
+    print("[reference deps on this box] " + ", ".join("%s: %s" % (k, "importable" if v else "absent") for k, v in have.items())
+          + ("  -> run tests/golden/make_reference_golden.py here to pin the oracle" if all(have.values()) else ""))
     # the -m gpu suite certifies the PRODUCT library: an I2I_LIB override (measurement builds) must not ride along silently
     assert os.path.realpath(lib.path) == os.path.realpath(_capi.DEFAULT_LIB), "I2I_LIB points the GPU tests at %s" % lib.path
     return lib

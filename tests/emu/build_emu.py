@@ -16,8 +16,8 @@ CSRC = os.path.join(ROOT, "img2img-turbo_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 # "<file>#<n>": conv3x3_w32.hip as four translation units (-DW32_PART=n, one family of instantiations each: csrc/build.py) -- the
 # whole file in one unit is 20 minutes of host clang
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip",
-           "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "calib.hip", "plan_file.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_w32.hip#0", "conv3x3_w32.hip#1", "conv3x3_w32.hip#2", "conv3x3_w32.hip#3", "gemm_dma.hip", "gemm_w32.hip#0", "gemm_w32.hip#1",
+           "conv_narrow.hip", "norm.hip", "elementwise.hip", "lora_merge.hip", "resize.hip", "attention.hip", "capi.hip", "calib.hip", "plan_file.hip"]
 OUT = os.path.join(HERE, "build", "libi2i_turbo_emu.so")
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-include", os.path.join(HERE, "hip_emu.h"),
          "-Wno-unused-function", "-Wno-unknown-attributes"]

@@ -40,6 +40,13 @@ def _cfg2():
     return lambda: pix2pix_forward(mw, x[[0, 7]], cap, eps[[0, 7]], return_intermediates=True)
 
 
+def _cfg2_all():
+    mw = make_pix2pix_weights(SD_TURBO_UNET, SD_TURBO_VAE, seed=1234 + 2)
+    x, cap, eps, _ = make_inputs("canny", 8, 512, 512, CD, seed=2)
+    x[5], eps[5] = x[0], eps[0]
+    return lambda: pix2pix_forward(mw, x, cap, eps, return_intermediates=True)
+
+
 def _cfg3(direction):
     def build():
         mw = make_cyclegan_weights(SD_TURBO_UNET, SD_TURBO_VAE)
@@ -82,6 +89,9 @@ def _floor512():
 
 CONFIGS = {
     "cfg2_pix2pix_bf16_bs8_512": (torch.bfloat16, _cfg2),
+    # all eight images of the benchmarked batch (round 6), and the same batch in the per-network precision mode (fp16 UNet, bf16 VAE)
+    "cfg2_pix2pix_bf16_bs8_512_all8": (torch.bfloat16, _cfg2_all),
+    "cfg2_pix2pix_mixed_unet_f16_vae_bf16_bs8_512": ((torch.bfloat16, torch.float16), _cfg2),
     "cfg3_cyclegan_a2b_bf16_bs4_512": (torch.bfloat16, _cfg3("a2b")),
     "cfg3_cyclegan_b2a_bf16_bs4_512": (torch.bfloat16, _cfg3("b2a")),
     "cfg4_stochastic_r0.4_bf16_bs16_512": (torch.bfloat16, _cfg4(0.4, [0, 15])),
@@ -105,7 +115,7 @@ def main():
         t0 = time.time()
         fwd = build()
         ref, ri = fwd()
-        with quantized(dtype):
+        with (quantized(*dtype) if isinstance(dtype, tuple) else quantized(dtype)):
             emu, ei = fwd()
         d = (emu - ref)
         rec[name] = {"dtype": str(dtype).replace("torch.", ""), "images": int(ref.shape[0]), "size": int(ref.shape[-1]),

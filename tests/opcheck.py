@@ -505,35 +505,3 @@ def check_ln_gemm(lib, device, dtype, *, rows=200, cin=128, nq=160, nv=0, geglu=
             err = max(err, rel_err(out2.cpu(), full[:, nq:].T))
     assert err < TOL[dtype], f"ln gemm rel err {err}"
     return err
-
-
-def check_gn_norm(lib, device, dtype, *, n=2, c0=32, c1=0, h=9, w=7, groups=8, act=1, eps=1e-5, seed=0, offset=0.0, slices=None):
-    """GroupNorm statistics + apply (+ SiLU) as one op (i2i_gn_norm) against F.group_norm on the rounded input; a second run must give
-    the same bits."""
-    g = torch.Generator().manual_seed(seed)
-    ct = c0 + c1
-    x = torch.randn(n, ct, h, w, generator=g) * 1.5 + 0.3 + offset
-    gamma = 1 + 0.1 * torch.randn(ct, generator=g)
-    beta = 0.1 * torch.randn(ct, generator=g)
-    xq = x.to(dtype).float()
-    ref = F.group_norm(xq.double(), groups, gamma.double(), beta.double(), eps).float()
-    if act:
-        ref = F.silu(ref)
-    x0 = nhwc(x[:, :c0], dtype).to(device)
-    x1 = nhwc(x[:, c0:], dtype).to(device) if c1 else None
-    S = slices or int(lib.lib.i2i_gn_norm_slices(n, h * w, ct))
-    partial = torch.zeros(n * S * groups * 2, device=device)
-    y = torch.full((n, h, w, ct), float("nan"), dtype=dtype, device=device)
-    gd, bd = gamma.to(device), beta.to(device)
-    opcode, p = O.gn_norm(x0, y, gd, bd, partial, nimg=n, hw=h * w, groups=groups, eps=eps, act=act, nslices=S,
-                          x1=x1, c0=c0, c1=c1, ld0=c0, ld1=c1, ldy=ct)
-    run_op(lib, opcode, p, dtype, device)
-    got = y.cpu().float().permute(0, 3, 1, 2)
-    err = float((got - ref).abs().max())
-    tol = {torch.float32: 2e-4, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype] * max(1.0, float(ref.abs().max()))
-    assert err < tol, f"gn_norm abs err {err} (tol {tol})"
-    first = y.clone()
-    y.fill_(float("nan"))
-    run_op(lib, opcode, p, dtype, device)
-    assert torch.equal(y, first), "gn_norm is not run-to-run identical"
-    return err

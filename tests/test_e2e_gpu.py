@@ -263,24 +263,37 @@ def _free(*objs):
 
 def test_cfg2_pix2pix_bf16_bs8_512(gpu_lib):
     """configs[1], the benchmarked configuration: edge_to_image, bf16, bs=8, 512x512 through the hipGraph path.
-    Oracle on images 0 and 7; the batch slots in between are covered by the slot-consistency check (image 0 fed again in
-    slot 5 must come out bit-identical: the kernels are deterministic and per-image independent) and by the fp32 route check:
-    bs=8 and bs=1 take different kernels for some convs (halo_min_tiles) and must agree to fp32 round-off."""
+    Oracle on ALL EIGHT images of the batch (round 6; ~8 s per image at 32 host threads), each held against the recorded floor of the
+    batch; image 0 fed again in slot 5 must come out bit-identical (the kernels are deterministic and per-image independent); the
+    per-network precision mode (fp16 UNet beside the bf16 VAE) on the same batch against ITS floor; and the fp32 route check: bs=8
+    and bs=1 take different kernels for some convs (halo_min_tiles) and must agree to fp32 round-off."""
     mw = sd_weights("pix2pix", seed=1234 + 2)
     x, cap, eps, _ = make_inputs("canny", 8, 512, 512, SD_TURBO_UNET.cross_attention_dim, seed=2)
     x[5], eps[5] = x[0], eps[0]
-    ref = oracle_cached("cfg2", lambda: pix2pix_forward(mw, x[[0, 7]], cap, eps[[0, 7]]))
+    ref_all = oracle_cached("cfg2_all8", lambda: pix2pix_forward(mw, x, cap, eps))
+    ref = ref_all[[0, 7]]
     t0 = time.perf_counter()
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16)
     out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
     torch.cuda.synchronize()
     print(f"[phase] cfg2 model build + pack + plan + first forward (bf16): {time.perf_counter() - t0:.1f} s")
     check_floor("cfg2 pix2pix bf16 bs=8 512x512 (images 0,7)", out[[0, 7]], ref, "cfg2_pix2pix_bf16_bs8_512")
+    check_floor("cfg2 pix2pix bf16 bs=8 512x512 (all 8 images)", out, ref_all, "cfg2_pix2pix_bf16_bs8_512_all8")
+    for i in range(8):          # no single image hides behind the batch statistics: each within the batch floor's gates on its own
+        check_floor(f"cfg2 image {i}", out[i:i + 1], ref_all[i:i + 1], "cfg2_pix2pix_bf16_bs8_512_all8")
     assert torch.equal(out[0], out[5]), "same image in another batch slot must give the same bits"
+    rms_bf16 = (out.float().cpu() - ref_all).pow(2).mean().sqrt().item()
+    _free(model)
+    model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.bfloat16, unet_dtype=torch.float16)
+    outm = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
+    check_floor("cfg2 mixed (fp16 UNet, bf16 VAE) bs=8 (images 0,7)", outm[[0, 7]], ref, "cfg2_pix2pix_mixed_unet_f16_vae_bf16_bs8_512")
+    rms_mixed = (outm.float().cpu() - ref_all).pow(2).mean().sqrt().item()
+    print(f"[parity] cfg2 all-8 RMS: bf16 {rms_bf16:.3e}, mixed {rms_mixed:.3e}")
+    assert rms_mixed < rms_bf16
     _free(model)
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float32)
     out8 = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
-    check("cfg2 fp32 bs=8 (images 0,7)", out8[[0, 7]], ref, torch.float32)
+    check("cfg2 fp32 bs=8 (all 8 images)", out8, ref_all, torch.float32)
     out1 = model(x[7:8].cuda(), caption_enc=cap.cuda(), eps=eps[7:8].cuda())
     d = (out8[7:8] - out1).abs().max().item()
     print(f"[parity] fp32 route agreement bs=8 vs bs=1: {d:.3e}")
@@ -358,14 +371,20 @@ def test_cfg4_stochastic_bf16_bs16_512(gpu_lib):
 
 
 def test_cfg5_pix2pix_fp16_1024(gpu_lib):
-    """configs[4] correctness at its own resolution: 1024x1024 fp16 (T = 16384 tokens through the d=512 wide-head attention
-    and the d=64 UNet attention, 1024^2 halo planes), GPU batch 2, oracle on image 1."""
+    """configs[4] correctness at its own resolution AND its benchmarked per-GPU batch: 1024x1024 fp16, 8 images (T = 16384 tokens
+    through the d=512 wide-head attention and the d=64 UNet attention, 1024^2 halo planes, the batch-8 kernel routes).  The batch
+    is the two seeded images four times over: the oracle (minutes per 1024^2 image on the host) runs on image 1, slots 3, 5 and 7 must
+    reproduce slot 1 bit for bit."""
     mw = sd_weights("pix2pix", seed=1234 + 5)
     x, cap, eps, _ = make_inputs("canny", 2, 1024, 1024, SD_TURBO_UNET.cross_attention_dim, seed=5)
     ref = oracle_cached("cfg5", lambda: pix2pix_forward(mw, x[1:2], cap, eps[1:2], return_intermediates=True))[0]
     model = Pix2Pix_Turbo(weights=gw(mw), device="cuda", dtype=torch.float16)
-    out = model(x.cuda(), caption_enc=cap.cuda(), eps=eps.cuda())
-    check_floor("cfg5 pix2pix fp16 bs=2 1024x1024 (image 1)", out[1:2], ref, "cfg5_pix2pix_f16_1024")
+    x8, e8 = x.repeat(4, 1, 1, 1), eps.repeat(4, 1, 1, 1)
+    out = model(x8.cuda(), caption_enc=cap.cuda(), eps=e8.cuda())
+    check_floor("cfg5 pix2pix fp16 bs=8 1024x1024 (image 1)", out[1:2], ref, "cfg5_pix2pix_f16_1024")
+    for i in (3, 5, 7):
+        assert torch.equal(out[i], out[1]), f"slot {i} differs from slot 1"
+    assert torch.equal(out[0], out[6])
     _free(model)
 
 

@@ -558,20 +558,6 @@ def test_gemm_w32_routing(emu_lib):
         del os.environ["I2I_GEMM_W32"]
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-def test_gn_norm_one_launch(emu_lib, dtype):
-    """GroupNorm statistics + apply as one op (slice statistics launch, finalize-and-apply launch)."""
-    oc.check_gn_norm(emu_lib, "cpu", dtype)
-    oc.check_gn_norm(emu_lib, "cpu", dtype, c0=40, c1=24, groups=4, h=5, w=5)                 # two sources, a group straddles the seam
-    oc.check_gn_norm(emu_lib, "cpu", dtype, c0=320, groups=32, h=8, w=8, n=1, act=0)          # cpg 10
-
-
-def test_gn_norm_wide_and_offset(emu_lib):
-    oc.check_gn_norm(emu_lib, "cpu", torch.float32, c0=1280, c1=1280, groups=32, h=4, w=4, n=1)      # two unit rounds per thread
-    oc.check_gn_norm(emu_lib, "cpu", torch.float32, offset=100.0, h=16, w=16)                         # shifted sums: no cancellation
-    oc.check_gn_norm(emu_lib, "cpu", torch.bfloat16, n=3, c0=64, h=9, w=11, groups=8, slices=5)
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm_folded_into_the_wide_gemm(emu_lib, dtype):
     oc.check_ln_gemm(emu_lib, "cpu", dtype)
@@ -603,3 +589,14 @@ def test_gn_stats_flag_boundaries(emu_lib):
         for mean in (lo, hi):
             oc.check_gn_stats_offset(emu_lib, "cpu", dtype, h=24, w=20, mean=mean, std=1.0, finalize_only=True, nparts=96)
             oc.check_gn_stats_offset(emu_lib, "cpu", dtype, h=24, w=20, mean=mean, std=1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_narrow_input_conv(emu_lib, dtype):
+    """conv_narrow.hip (tile 60): the VAE's conv_in shape class -- 3 (padded to 8) input channels into a multiple of 128 output
+    channels, 3x3 s1 p1 -- incl. ragged tiles and the GroupNorm partial sums of its output."""
+    oc.check_conv(emu_lib, "cpu", dtype, n=2, cin=3, cout=128, h=16, w=64, tile=60)
+    oc.check_conv(emu_lib, "cpu", dtype, n=1, cin=3, cout=256, h=9, w=40, tile=60, bias=False, seed=3)       # ragged in both directions, two channel tiles
+    oc.check_conv(emu_lib, "cpu", dtype, n=1, cin=8, cout=128, h=8, w=32, tile=60, seed=4)                    # all 8 input channels live
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=2, cin=3, cout=128, h=16, w=64, groups=32, tile=60, res=False)
+    oc.check_conv_gn_part(emu_lib, "cpu", dtype, n=1, cin=3, cout=128, h=12, w=40, groups=16, tile=60, res=False, seed=2)

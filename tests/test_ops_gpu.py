@@ -322,21 +322,6 @@ def test_gn_stats_large_offset_second_pass(gpu_lib):
     oc.check_gn_stats_offset(gpu_lib, "cuda", torch.float16, n=1, c=512, h=64, w=64, groups=32, mean=200.0, std=0.2, nparts=16)   # cpg 16: 16-byte pieces
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-def test_gn_norm_one_launch(gpu_lib, dtype):
-    """GroupNorm statistics + apply as one op (i2i_gn_norm): the UNet's resnet / transformer inputs at batch 1 and 8, concat inputs
-    whose groups straddle the two sources, a tensor on a DC offset (the shifted sums must not cancel), several slice counts."""
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=320, h=64, w=64, groups=32)
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=1, c0=320, h=64, w=64, groups=32)
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=640, c1=320, h=64, w=64, groups=32)          # cpg 30: groups straddle the seam
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=1, c0=1280, c1=1280, h=8, w=8, groups=32)          # two unit rounds per thread
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=8, c0=1280, c1=640, h=16, w=16, groups=32, act=0)
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=3, c0=640, h=33, w=41, groups=32)                  # ragged slices
-    oc.check_gn_norm(gpu_lib, "cuda", dtype, n=2, c0=128, h=48, w=40, groups=32, offset=100.0)
-    for s in (1, 2, 7, 32, 64):
-        oc.check_gn_norm(gpu_lib, "cuda", dtype, n=2, c0=320, h=32, w=32, groups=32, slices=s, seed=s)
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm_folded_into_the_wide_gemm(gpu_lib, dtype):
     """LayerNorm + linear in one launch (i2i_igemm_params.ln_cs) incl. the merge that folds the LayerNorm weight: every tile
@@ -360,3 +345,13 @@ def test_gn_stats_flag_boundaries(gpu_lib):
         for mean in (lo, hi):
             oc.check_gn_stats_offset(gpu_lib, "cuda", dtype, h=64, w=64, mean=mean, std=1.0, finalize_only=True, nparts=512)
             oc.check_gn_stats_offset(gpu_lib, "cuda", dtype, h=64, w=64, mean=mean, std=1.0, sliced=True, nparts=20)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_narrow_input_conv(gpu_lib, dtype):
+    """conv_narrow.hip: the VAE's conv_in (3 -> 128 at full resolution) as a write-bound kernel of its own; auto route (tile 0) on a
+    plane of at least 256 tiles, forced (tile 60) on ragged ones; GroupNorm partial sums of the output."""
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=3, cout=128, h=256, w=256, tile=0)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=3, cout=256, h=50, w=72, tile=60, bias=False, seed=3)
+    oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=3, cout=128, h=128, w=128, groups=32, tile=0, res=False)
+    oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=3, cout=128, h=44, w=72, groups=32, tile=60, res=False, seed=5)
