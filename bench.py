@@ -130,8 +130,8 @@ def kernel_roofline(plan, dtype_name, reps=2):
     # one read [+ one write] per element): algorithmic GB/s against the 8 TB/s HBM3E peak
     breakdown = {k: {"ms": round(v[0], 3), "launches": v[2], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None,
                      "frac_of_mfma_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4) if v[1] else None,
-                     "gbytes_per_s": round(v[4] / (v[0] * 1e-3) / 1e9, 1) if (v[4] and not v[1]) else None,
-                     "frac_of_hbm_peak": round(v[4] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (v[4] and not v[1]) else None}
+                     "gbytes_per_s": round(v[4] / (v[0] * 1e-3) / 1e9, 1) if v[4] else None,
+                     "frac_of_hbm_peak": round(v[4] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[4] else None}
                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     return roof, breakdown, tot
 

@@ -12,6 +12,7 @@
 // Running max / sum / rescale all belong to query l&15 = this lane: no cross-lane traffic except two
 // xor-shuffles (16, 32) per tile for the max.  V arrives transposed (V^T [heads*d][Tk]) straight from the
 // projection GEMM (weights as the A operand), so no transpose pass exists anywhere.
+#include <stdlib.h>
 #include <type_traits>
 #include "i2i_dev.h"
 #include "launch.h"
@@ -234,17 +235,19 @@ __device__ __forceinline__ int att_koff(int row, int kc) { return row * 128 + ((
 // the key (inside its 64-key tile) that row m of score fragment kf holds
 __device__ __forceinline__ int att_key_of(int kf, int m) { return 32 * (kf >> 1) + 8 * (m >> 2) + 4 * (kf & 1) + (m & 3); }
 
-template <typename T>
+// QF = query fragments per wave: 2 (128 queries per workgroup) for the launches that fill the chip, 1 (64 queries, twice the
+// workgroups) for the small grids of a batch-1 forward, where a workgroup's 64 serial key tiles are the launch.
+template <typename T, int QF>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attention_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit types only");
-    constexpr int D = 64, BKV = 64, QF = 2, STAGE = 2 * BKV * 128, PPW = 4;   // 16 one-KiB pieces per stage, 4 per wave
+    constexpr int D = 64, BKV = 64, QT = 64 * QF, STAGE = 2 * BKV * 128, PPW = 4;   // 16 one-KiB pieces per stage, 4 per wave
     constexpr float LAZY = 8.0f;                                              // log2 units a score may exceed its reference by
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     int qt, h, b;
-    if (!att_group_of_block((p.tq + 127) / 128, p.heads, p.batch, qt, h, b)) return;
-    const int q0 = qt * 128 + wave * 32;
+    if (!att_group_of_block((p.tq + QT - 1) / QT, p.heads, p.batch, qt, h, b)) return;
+    const int q0 = qt * QT + wave * (16 * QF);
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
                 for (int r = 0; r < 4; ++r) mt[f] = fmaxf(mt[f], sacc[f][kf][r]);
         }
         // ---- slow path (first tile; some score more than 2^LAZY above its reference): move the references ----
-        if (t == 0 || wave_any(fmaxf(mt[0], mt[1]) > LAZY)) {
+        if (t == 0 || wave_any(fmaxf(mt[0], mt[QF - 1]) > LAZY)) {
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 const float m = quad_max(mt[f]);
@@ -762,8 +765,12 @@ int launch_att_wide(const i2i_attention_params& p, hipStream_t s) {
 
 template <typename T>
 int launch_att_dma(const i2i_attention_params& p, hipStream_t s) {
-    const dim3 grid(att_grid((p.tq + 127) / 128, p.heads, p.batch));
-    hipLaunchKernelGGL((attention_dma_kernel<T>), grid, dim3(256), (size_t)3 * 2 * 64 * 128, s, p);
+    const unsigned g2 = att_grid((p.tq + 127) / 128, p.heads, p.batch);
+    const size_t smem = (size_t)3 * 2 * 64 * 128;
+    const char* e = getenv("I2I_ATT_QF");                  // test / A-B hook: force the 128-query (2) or the 64-query (1) workgroup
+    const int force = e ? atoi(e) : 0;
+    if (force == 2 || (force != 1 && g2 >= 384)) hipLaunchKernelGGL((attention_dma_kernel<T, 2>), dim3(g2), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((attention_dma_kernel<T, 1>), dim3(att_grid((p.tq + 63) / 64, p.heads, p.batch)), dim3(256), smem, s, p);
     return i2i::check_launch("attention_dma");
 }
 

@@ -659,6 +659,7 @@ int launch_dma_t(const i2i_igemm_params& p, hipStream_t s) {
         case 23: return launch_dma<T, 64, 128, 2, 2, 2>(p, s);    // small M (weight streaming), 72 KiB
         case 24: return launch_dma<T, 64, 64, 2, 2, 2>(p, s);     // 48 KiB, 3 workgroups / CU
         case 25: return launch_dma<T, 256, 128, 4, 2, 2>(p, s);   // 8 waves, 144 KiB
+        case 26: return launch_dma<T, 64, 32, 4, 1, 2>(p, s);     // few rows x short K (batch-1 linears): 36 KiB ring, enough tiles to fill the chip WITHOUT K slices
     }
     return i2i::fail(I2I_ERR_BAD_ARG, "igemm_dma: unknown tile config %d", cfg);
 }
@@ -710,6 +711,7 @@ int igemm_dma_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
         case 23: bm = 64; wtn = 64; break;
         case 24: bm = 64; wtn = 32; break;
         case 25: bm = 256; wtn = 64; break;
+        case 26: bm = 64; wtn = 32; break;
         default: return 0;
     }
     const int cpg = p.N / groups, hw = p.ho * p.wo;

@@ -130,6 +130,9 @@ class ForwardPlan:
         # with a tiny model)
         self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
         self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
+        self.small_tile_rows = int(os.environ.get("I2I_SMALL_TILE_ROWS", "4096"))   # see _small_tile (A/B hooks)
+        self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
+        self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
@@ -294,6 +297,17 @@ class ForwardPlan:
             return 0, None
         return sk, self.pool.get(sk * M * N, torch.float32)
 
+    def _small_tile(self, M, N, Kd):
+        """A linear / 1x1 conv of few rows and a SHORT K (the UNet's 320- and 640-wide projections at batch 1: 1024 / 4096 token rows) on
+        64 x 32 tiles of the LDS-DMA igemm (tile 26) when those alone fill the chip: one launch with the epilogue in it, instead of
+        K slices + the reduce launch, or of ~100 large tiles.  Only up to ~10 K steps: the engine's ring is three stages deep, so an
+        un-sliced K loop costs one memory latency per three steps (measured at batch 1, profiles/r6g_*: 256 rows x K = 1280 un-sliced
+        17.0 us against 15.5 us sliced + reduced, K = 5120 45 against 24; 1024 rows x K = 640 13.4 against 16.0).
+        I2I_SMALL_TILE_ROWS / _K = row / K limits (0 rows = off)."""
+        if self.dtype == torch.float32 or M > self.small_tile_rows or Kd % 64 or Kd > self.small_tile_k or N % 8:
+            return False
+        return -(-M // 64) * -(-N // 32) >= self.small_tile_min_tiles
+
     @staticmethod
     def _w32_splitk_cfg(M, N, Kd, min_wgs=96):
         """(wide-GEMM tile id, K slices) for a small-plane 3x3 convolution; (0, 0) = leave it on the LDS-DMA igemm.
@@ -407,7 +421,10 @@ class ForwardPlan:
                 self._pending_gn.append((op[1], "apply"))
                 self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
-        splitk, ws = (0, None) if (halo or fused or geglu) else self._splitk(M, N, Kd)
+        if (ks == 1 and stride == 1 and not ups and not (halo or fused or geglu or out_f32) and force_tile in (0, 20)
+                and self._small_tile(M, N, Kd)):
+            tile_was, force_tile = force_tile, 26
+        splitk, ws = (0, None) if (halo or fused or geglu or force_tile == 26) else self._splitk(M, N, Kd)
         mk = lambda tile_, splitk_, ws_: O.conv(
             x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
             x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
@@ -436,6 +453,10 @@ class ForwardPlan:
                         self.pool.put(ws2)
         if op is None:
             op = mk(force_tile, splitk, ws)
+            if force_tile == 26 and self.lib.igemm_route(op[1], self.dt) != "igemm_dma_kernel":     # (not taken by the engine: the old decision)
+                force_tile = tile_was
+                splitk, ws = self._splitk(M, N, Kd)
+                op = mk(force_tile, splitk, ws)
         if ws is not None:
             self.pool.put(ws)      # the program runs in order on one stream: later ops may reuse the slab
         out.producer = op[1]
@@ -476,7 +497,9 @@ class ForwardPlan:
         fl += fl_k2
         if kname.startswith("conv3x3_"):
             self.halo_flops_real = getattr(self, "halo_flops_real", 0) + fl_exec
-        self._add(op, label, fl, kernel=kname, flops_exec=fl_exec)
+        # the narrow-end convs (conv_narrow.hip) are HBM streams: priced in bytes as well (one read of the input, one write of the output)
+        nb = (x.n * hin * win * (x.c + c1) + x.n * ho * wo * out.c) * self.esz if kname.startswith("conv_narrow") else 0
+        self._add(op, label, fl, kernel=kname, flops_exec=fl_exec, nbytes=nb)
         self.taps[label] = out
         if gn and not fused:
             self.free(x_in0)
@@ -489,13 +512,21 @@ class ForwardPlan:
         out_cols = out_cols or n_out
         if out is None:
             out = self.pool.get(rows * out_cols, self.dtype)
-        splitk, ws = (0, None) if geglu else self._splitk(rows, pw["n"], cin)
+        mk = lambda tile_, splitk_, ws_: O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
+                                                res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu, splitk=splitk_, ws=ws_, tile=tile_)
         # (round 6, measured negative: the K-sliced small linears -- a split-K launch + its reduce launch -- as ONE un-sliced wide-GEMM launch
-        # with a handful of tiles: +0.06 ... +0.32 ms at batch 1 for row limits 64 ... 4096, neutral at batch 8; profiles/r6d_ab_bs1_unsplit.log)
-        op = O.conv(x2d, pw["w"], out, nimg=1, hin=1, win=rows, ho=1, wo=rows, ks=1, c0=cin, lda0=cin, N=pw["n"], bias=pw["b"],
-                    res=res, ldr=n_out if res is not None else None, ldc=out_cols, geglu=geglu, splitk=splitk, ws=ws)
-        if ws is not None:
-            self.pool.put(ws)
+        # with a handful of tiles: +0.06 ... +0.32 ms at batch 1 for row limits 64 ... 4096, neutral at batch 8; profiles/r6d_ab_bs1_unsplit.log.
+        # What does pay is the un-sliced launch on tiles small enough to fill the chip: _small_tile)
+        op = None
+        if not geglu and self._small_tile(rows, pw["n"], cin):
+            op = mk(26, 0, None)
+            if self.lib.igemm_route(op[1], self.dt) != "igemm_dma_kernel":
+                op = None
+        if op is None:
+            splitk, ws = (0, None) if geglu else self._splitk(rows, pw["n"], cin)
+            op = mk(0, splitk, ws)
+            if ws is not None:
+                self.pool.put(ws)
         self._add(op, label, 2 * rows * pw["n"] * cin, kernel=self.lib.igemm_route(op[1], self.dt))
         self.flops += 2 * rows * pw["n"] * cin
         return out

@@ -164,6 +164,24 @@ def test_dma_igemm_geglu_bgemm(emu_lib, dtype):
     oc.check_bgemm(emu_lib, "cpu", dtype, out_f32=0, tile=22)
 
 
+def test_conv_narrow_output(emu_lib):
+    """conv_narrow_out_kernel (VAE decoder conv_out: 128 -> 3 with GroupNorm + SiLU applied on the way in): ragged strips (w % 32),
+    segments of 8 rows with a ragged last step (h % 4), 4 output channels, no norm, both 16-bit types."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=3, h=20, w=40, gn=True, act=1, groups=32, tile=60)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=4, h=9, w=33, tile=60, alpha=0.7)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=1, h=6, w=8, gn=True, act=0, groups=8, bias=False, tile=60)
+
+
+def test_dma_igemm_small_tile(emu_lib):
+    """Tile 26 (64 x 32, four waves along the rows): the batch-1 linears without K slices -- ragged rows / columns, residual, the
+    two-source 1x1 (conv_shortcut of a concat), a K tail, fp32."""
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=320, cout=328, h=16, w=17, ks=1, pad=0, res=True, tile=26)
+    oc.check_conv(emu_lib, "cpu", torch.float16, n=2, cin=64, cin2=128, cout=72, h=7, w=9, ks=1, pad=0, tile=26)
+    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=1, cin=88, cout=40, h=8, w=9, ks=1, pad=0, res=True, alpha=0.7, tile=26)
+    oc.check_conv(emu_lib, "cpu", torch.float32, n=1, cin=96, cout=56, h=8, w=8, ks=1, pad=0, tile=26)
+    oc.check_conv_gn_part(emu_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=128, h=16, w=16, groups=32, tile=26, ks=1)
+
+
 @pytest.mark.parametrize("wgs", [1, 2, 3, 5])
 def test_dma_igemm_persistent_stream(emu_lib, wgs, monkeypatch):
     """Persistent launch (fewer workgroups than tiles; I2I_PERSIST_WGS is the test hook): the K-step stream crosses
@@ -235,9 +253,11 @@ def test_gn_stats_single_launch_shapes(emu_lib):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_attention_dma_ring_and_tails(emu_lib, dtype):
+@pytest.mark.parametrize("qf", ["1", "2"])
+def test_attention_dma_ring_and_tails(emu_lib, dtype, qf, monkeypatch):
     """attention_dma_kernel: >3 key tiles (ring wrap-around), query tails across workgroups, tk a multiple of 64,
     tk with a partially valid last V^T chunk (padding poisoned with NaN by the checker)."""
+    monkeypatch.setenv("I2I_ATT_QF", qf)                   # 64-query (small grids) and 128-query workgroups
     oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=2, tq=130, tk=264)
     oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, tq=33, tk=64)
     oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, tq=128, tk=325, spike=True)

@@ -155,6 +155,17 @@ def test_gemm_w32_conv3x3_gather_on_hardware(gpu_lib, cfg):
 
 
 @pytest.mark.gpu
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dma_igemm_small_tile(gpu_lib, dtype):
+    """Tile 26 (64 x 32): the UNet's batch-1 projections as one un-sliced launch (256 / 1024 token rows, K = 640 .. 5120)."""
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=1280, cout=1280, h=16, w=16, ks=1, pad=0, res=True, tile=26)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=5120, cout=1280, h=16, w=16, ks=1, pad=0, res=True, tile=26)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=640, cout=640, h=32, w=32, ks=1, pad=0, tile=26)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=1280, cin2=640, cout=640, h=32, w=32, ks=1, pad=0, tile=26)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=320, cout=328, h=16, w=17, ks=1, pad=0, res=True, tile=26)
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dma_igemm_geglu_bgemm_splitk(gpu_lib, dtype):
     oc.check_geglu(gpu_lib, "cuda", dtype, tile=20, rows=300, cin=320, cff=1280)
@@ -355,3 +366,14 @@ def test_narrow_input_conv(gpu_lib, dtype):
     oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=3, cout=256, h=50, w=72, tile=60, bias=False, seed=3)
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=3, cout=128, h=128, w=128, groups=32, tile=0, res=False)
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=3, cout=128, h=44, w=72, groups=32, tile=60, res=False, seed=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_narrow_output_conv(gpu_lib, dtype):
+    """conv_narrow_out_kernel: the VAE decoder's conv_out (128 -> 3 at full resolution, GroupNorm + SiLU applied on the way in) as a
+    read-bound kernel of its own; auto route (tile 0) on a plane of at least 256 workgroups, forced (tile 60) on ragged ones."""
+    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=3, h=256, w=256, gn=True, act=1, groups=32, tile=0)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cout=3, h=512, w=512, gn=True, act=1, groups=32, tile=0, seed=2)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cout=4, h=50, w=72, tile=60, bias=False, seed=3)
+    oc.check_conv(gpu_lib, "cuda", dtype, n=3, cin=128, cout=3, h=37, w=95, gn=True, act=1, groups=32, tile=60, alpha=0.5, seed=4)
