@@ -14,7 +14,6 @@
 //     (v_dot2c on the stored pairs, rows -> wave through an LDS transpose in a fixed order, one slot per (tile, group)).
 // 16-bit types; everything else (and every other shape) stays on the LDS-DMA igemm.
 #include <stdlib.h>
-#include <type_traits>
 
 #include "i2i_dev.h"
 #include "launch.h"
@@ -165,145 +164,6 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const i2i_igemm_par
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// 3x3 convolution of a WIDE input into a NARROW output (cout <= 4) with the GroupNorm + SiLU in front of it applied on the way in: the
-// VAE decoder's conv_out (diffusers Decoder.conv_norm_out -> conv_act -> conv_out, 128 -> 3 at full resolution, reached from
-// src/model.py:52-54), replacing F.conv2d(F.silu(F.group_norm(x)), w) there.
-//
-// Why its own kernel: the launch is a pure READ stream -- 537 MB of input for 33 MB of output at batch 8, 512 x 512 -- and ran on the
-// halo-tiled MFMA conv with 3 of its 128 output columns live (0.26 ms, 2.0 TB/s; profiles/r6e_per_op_bs8.txt).  Here
-//   * a workgroup (4 waves) owns a strip of 32 columns x `seg` rows of one image and walks down it 4 rows at a time; the transformed
-//     rows live in an LDS ring of 8 rows x 34 pixels x 256 B (the column halo is the only redundancy: 34 / 32, plus 2 rows per segment),
-//     two workgroups per CU, so one's HBM latency and VALU transform hide under the other's contraction;
-//   * per step: the 4 new rows come in as 16-byte chunks (a thread keeps ONE channel chunk for its whole life: its 8 scale / shift
-//     pairs are loop invariant), are normalised + activated in registers and written to LDS (chunk ^ pixel & 15: conflict-free both
-//     ways); the loads of the NEXT step are issued before the contraction of this one;
-//   * contraction: v_mfma_f32_16x16x32 with the weights as the A operand (rows = output channels, 36 fragments = 9 taps x 4 channel
-//     chunks of 32, resident in registers) and 16 pixels of one row as the B operand -- one ds_read_b128 per MFMA at (row + ky,
-//     column + kx); a wave owns one row of the step (two 16-pixel groups);
-//   * lanes 0-15 then hold the <= 4 output channels of their pixel: bias, round, one 16-byte store of the 8-channel padded pixel.
-constexpr int CO_TW = 32, CO_R = 4, CO_RING = 8, CO_HW = CO_TW + 2, CO_C = 128, CO_ROW = CO_HW * CO_C * 2;
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_narrow_out_kernel(const i2i_igemm_params p, const int seg) {
-    typedef typename Elem<T>::chunk_t chunk_t;
-    typedef T tx8 __attribute__((ext_vector_type(8)));
-    static_assert(Elem<T>::EPC == 8, "16-bit types only");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    const int tw = (p.wo + CO_TW - 1) / CO_TW, nseg = (p.ho + seg - 1) / seg;
-    int b = blockIdx.x;
-    const int tx = b % tw; b /= tw;
-    const int sg = b % nseg, img = b / nseg;
-    const int x0 = tx * CO_TW, ys = sg * seg, ye = ys + seg < p.ho ? ys + seg : p.ho;
-    const int nstep = (ye - ys + CO_R - 1) / CO_R;
-
-    // ---- this thread's channel chunk: 8 (scale, shift) pairs of GroupNorm, loop invariant
-    const int ck = tid & 15, pp = tid >> 4;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-    if (p.gn_ss) {
-        const float* ss = p.gn_ss + ((int64_t)img * CO_C + ck * 8) * 2;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const f32x4 v = *(const f32x4*)(ss + 2 * j);
-            sc[j] = v[0]; sh[j] = v[1]; sc[j + 1] = v[2]; sh[j + 1] = v[3];
-        }
-    }
-    const bool silu = p.act == 1;
-    const T* src = (const T*)p.a0 + (int64_t)img * p.hin * p.win * p.lda0 + ck * 8;
-    // rows y .. y + NR - 1 of the strip (34 pixels each) as chunks ck of pixels pp, pp + 16, ...: raw loads, then transform + LDS write
-    constexpr int NI4 = (CO_R * CO_HW + 15) / 16, NI2 = (2 * CO_HW + 15) / 16;
-    auto load_rows = [&](chunk_t* r, int y, auto nic, int nr) __attribute__((always_inline)) {
-        constexpr int NI = decltype(nic)::value;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int px = pp + 16 * i, row = px / CO_HW, col = px - row * CO_HW;
-            const int yy = y + row, xx = x0 - 1 + col;
-            const bool ok = row < nr && (unsigned)yy < (unsigned)p.hin && (unsigned)xx < (unsigned)p.win;
-            r[i] = ok ? *(const chunk_t*)(src + ((int64_t)yy * p.win + xx) * p.lda0) : zero_chunk<T>();
-        }
-    };
-    auto store_rows = [&](const chunk_t* r, int y, auto nic, int nr) __attribute__((always_inline)) {
-        constexpr int NI = decltype(nic)::value;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int px = pp + 16 * i, row = px / CO_HW, col = px - row * CO_HW;
-            const int yy = y + row, xx = x0 - 1 + col;
-            if (row >= nr) continue;
-            const bool ok = (unsigned)yy < (unsigned)p.hin && (unsigned)xx < (unsigned)p.win;
-            chunk_t o = zero_chunk<T>();                    // zero padding is applied AFTER norm + activation (F.conv2d pads its input)
-            if (ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = __builtin_fmaf((float)r[i][j], sc[j], sh[j]);
-                    if (silu) v = silu_f(v);
-                    o[j] = (T)v;
-                }
-            }
-            *(chunk_t*)(i2i_smem + ((yy + 1) & (CO_RING - 1)) * CO_ROW + col * (CO_C * 2) + ((ck ^ (col & 15)) << 4)) = o;
-        }
-    };
-    // ---- weights: A fragments, row lr = output channel (zero rows past N), tap t, channel chunk kc
-    chunk_t wf[9][4];
-    {
-        const T* wr = (const T*)p.b + (int64_t)(lr < p.N ? lr : 0) * p.ldb + lq * 8;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) wf[t][kc] = lr < p.N ? *(const chunk_t*)(wr + t * CO_C + kc * 32) : zero_chunk<T>();
-    }
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias_mode == 1 && p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < p.N) bias[r] = p.bias[r];
-    }
-    T* out = (T*)p.c + (int64_t)img * p.ho * p.wo * p.ldc;
-
-    chunk_t r2[NI2], r4[NI4];
-    load_rows(r2, ys - 1, std::integral_constant<int, NI2>{}, 2);
-    load_rows(r4, ys + 1, std::integral_constant<int, NI4>{}, CO_R);
-    store_rows(r2, ys - 1, std::integral_constant<int, NI2>{}, 2);
-    for (int s = 0; s < nstep; ++s) {
-        const int y = ys + s * CO_R;
-        store_rows(r4, y + 1, std::integral_constant<int, NI4>{}, CO_R);          // rows y+1 .. y+4 (the previous step is done with their slots)
-        if (s + 1 < nstep) load_rows(r4, y + CO_R + 1, std::integral_constant<int, NI4>{}, CO_R);
-        __syncthreads();
-        // ---- output row y + wave, pixel groups x0 .. +15 and x0 + 16 .. +31
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const char* rowp = i2i_smem + ((y + wave + ky) & (CO_RING - 1)) * CO_ROW;      // slot of image row y + wave + ky - 1
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        const int col = cb * 16 + lr + kx;
-                        const chunk_t xb = *(const chunk_t*)(rowp + col * (CO_C * 2) + (((kc * 4 + lq) ^ (col & 15)) << 4));
-                        acc[cb] = mma_chunk(wf[ky * 3 + kx][kc], xb, acc[cb]);
-                    }
-        }
-        const int yo = y + wave;
-        if (lq == 0 && yo < ye) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int xo = x0 + cb * 16 + lr;
-                if (xo < p.wo) {
-                    tx8 o;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (T)0.0f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < p.N) o[r] = from_f32<T>(__builtin_fmaf(p.alpha, acc[cb][r], bias[r]));
-                    *(tx8*)(out + ((int64_t)yo * p.wo + xo) * p.ldc) = o;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 }  // namespace
 
 namespace i2i {
@@ -335,45 +195,6 @@ int conv_narrow_gn_parts(const i2i_igemm_params& p, int dtype, int groups) {
     const int cpg = p.N / groups;
     if (cpg % 4 || CN_BN % cpg) return 0;
     return ((p.ho + CN_TH - 1) / CN_TH) * ((p.wo + CN_TW - 1) / CN_TW);
-}
-// What the narrow-output conv takes: a 16-bit 3x3 stride-1 pad-1 convolution of ONE 128-channel source into <= 4 channels stored as
-// 8-channel padded pixels, optional GroupNorm scale / shift + SiLU on the input, per-column bias or none, nothing else fused.
-bool conv_narrow_out_eligible(const i2i_igemm_params& p, int dtype) {
-    if (dtype != I2I_BF16 && dtype != I2I_F16) return false;
-    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.up_h || p.up_w || p.subpix) return false;
-    if (p.c0 != CO_C || p.c1 || p.a1 || p.lda0 % 8 || p.K != 9 * CO_C || p.ldb % 8 || p.ldb < 9 * CO_C) return false;
-    if (p.N < 1 || p.N > 4 || p.ldc != 8 || p.ho != p.hin || p.wo != p.win || p.M != p.nimg * p.ho * p.wo) return false;
-    if (p.act > 1 || p.act_out || p.res || p.geglu || p.out_f32 || p.splitk > 1 || p.k2_a || p.ln_cs || p.n_trans || p.c2 || p.gn_part) return false;
-    if (p.zcount > 1 || p.bias_mode == 2 || (p.bias_mode == 1 && !p.bias)) return false;
-    if (((uintptr_t)p.a0 | (uintptr_t)p.b | (uintptr_t)p.c | (uintptr_t)p.gn_ss) & 15) return false;
-    if ((int64_t)p.nimg * p.hin * p.win * p.lda0 * 2 >= (int64_t(1) << 40)) return false;
-    return true;
-}
-// rows per workgroup: the tallest segment that still puts >= 2 workgroups on every CU
-static int conv_narrow_out_seg(const i2i_igemm_params& p) {
-    const long strips = (long)p.nimg * ((p.wo + CO_TW - 1) / CO_TW);
-    int seg = 64;
-    while (seg > 8 && strips * ((p.ho + seg - 1) / seg) < 512) seg >>= 1;
-    return seg;
-}
-// tile == 0: the full-resolution planes (>= 256 workgroups of >= 8 rows); I2I_CONV_NARROW=0 switches the route off (A/B hook).
-bool conv_narrow_out_auto(const i2i_igemm_params& p, int dtype) {
-    if (!conv_narrow_out_eligible(p, dtype)) return false;
-    const char* e = getenv("I2I_CONV_NARROW");
-    if (e && atoi(e) == 0) return false;
-    const int seg = conv_narrow_out_seg(p);
-    return (long)p.nimg * ((p.wo + CO_TW - 1) / CO_TW) * ((p.ho + seg - 1) / seg) >= 256;
-}
-int conv_narrow_out(const i2i_igemm_params& p, int dtype, hipStream_t s) {
-    const int seg = conv_narrow_out_seg(p);
-    const dim3 grid((unsigned)(p.nimg * ((p.wo + CO_TW - 1) / CO_TW) * ((p.ho + seg - 1) / seg))), block(256);
-    const size_t smem = (size_t)CO_RING * CO_ROW;
-    switch (dtype) {
-        case I2I_BF16: hipLaunchKernelGGL((conv_narrow_out_kernel<__bf16>), grid, block, smem, s, p, seg); break;
-        case I2I_F16: hipLaunchKernelGGL((conv_narrow_out_kernel<_Float16>), grid, block, smem, s, p, seg); break;
-        default: return fail(I2I_ERR_BAD_ARG, "conv_narrow_out: bad dtype");
-    }
-    return check_launch("conv_narrow_out");
 }
 int conv_narrow(const i2i_igemm_params& p, int dtype, hipStream_t s) {
     const dim3 grid((unsigned)(p.nimg * ((p.ho + CN_TH - 1) / CN_TH) * ((p.wo + CN_TW - 1) / CN_TW)), (unsigned)(p.N / CN_BN)), block(256);

@@ -786,6 +786,13 @@ int g32_cfg(const i2i_igemm_params& p) {
     if (p.tile >= 51 && p.tile <= 56) return p.tile;
     const bool w160 = p.N % 160 == 0, w128 = p.N % 128 == 0;
     if (p.geglu && w160 && p.K < 1280) return 55;
+    // (A/B hook, I2I_G32_SHORTK = K limit: the plain short-K projections on the two-workgroups-per-CU form as well)
+    const char* e_sk = getenv("I2I_G32_SHORTK");          // (read per call: an A/B process changes it between plans)
+    const int shortk = e_sk ? atoi(e_sk) : 0;
+    if (shortk > 0 && !p.geglu && p.ks == 1 && p.splitk <= 1 && !p.gn_part && p.K <= shortk) {
+        if (w160 && g32_tiles(p, 55) >= 512) return 55;
+        if (w128 && g32_tiles(p, 56) >= 512) return 56;
+    }
     const int tall = w160 ? 51 : 53;
     if (g32_tiles(p, tall) >= 256) return tall;
     auto fill = [&](int cfg) { const long t = g32_tiles(p, cfg); return (double)t / (double)(((t + 255) / 256) * 256); };

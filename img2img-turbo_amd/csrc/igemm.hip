@@ -38,9 +38,6 @@ bool conv_narrow_eligible(const i2i_igemm_params& p, int dtype);    // conv_narr
 bool conv_narrow_auto(const i2i_igemm_params& p, int dtype);
 int conv_narrow_gn_parts(const i2i_igemm_params& p, int dtype, int groups);
 int conv_narrow(const i2i_igemm_params& p, int dtype, hipStream_t s);
-bool conv_narrow_out_eligible(const i2i_igemm_params& p, int dtype);    // conv_narrow.hip: 128 -> <= 4 channels with the norm in front (tile ids 60..69)
-bool conv_narrow_out_auto(const i2i_igemm_params& p, int dtype);
-int conv_narrow_out(const i2i_igemm_params& p, int dtype, hipStream_t s);
 }  // namespace i2i
 
 namespace {
@@ -339,15 +336,11 @@ extern "C" int i2i_igemm(const i2i_igemm_params* pp, int dtype, void* stream) {
     const bool w32_forced = p.tile >= 40 && p.tile <= 49;      // 32x32x16-MFMA wide-tile conv (conv3x3_w32.hip)
     if (w32_forced && !i2i::conv3x3_w32_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (w32 conv) not applicable", p.tile);
     if (w32_forced || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32(p, dtype, s);
-    // the narrow-OUTPUT 3x3 conv (VAE decoder conv_out: 128 -> 3 with GroupNorm + SiLU on the way in; conv_narrow.hip): ahead of the halo
-    // conv, which would take the op with 3 of its 128 columns live (tile 0 = auto, 60..69 = force)
-    if ((p.tile >= 60 && p.tile <= 69 && i2i::conv_narrow_out_eligible(p, dtype)) || (p.tile == 0 && i2i::conv_narrow_out_auto(p, dtype)))
-        return i2i::conv_narrow_out(p, dtype, s);
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_forced && !i2i::conv3x3_halo_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (halo conv) not applicable", p.tile);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo(p, dtype, s);
     // the narrow-input 3x3 conv (VAE conv_in: 8 padded input channels; conv_narrow.hip; tile 0 = auto, 60..69 = force)
-    if (p.tile >= 60 && p.tile <= 69 && !i2i::conv_narrow_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (narrow conv) not applicable", p.tile);
+    if (p.tile >= 60 && p.tile <= 69 && !i2i::conv_narrow_eligible(p, dtype)) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d (narrow-input conv) not applicable", p.tile);
     if ((p.tile >= 60 && p.tile <= 69) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return i2i::conv_narrow(p, dtype, s);
     // plain 16-bit GEMMs that fill the chip: the wide GEMM (32x32x16 MFMA, gemm_w32.hip; tile 0 = auto, 50..56 = force)
     if (p.tile >= 57 && p.tile <= 59) return i2i::fail(I2I_ERR_BAD_ARG, "igemm: tile %d is not a wide-GEMM configuration (50 = auto, 51..56)", p.tile);
@@ -372,7 +365,6 @@ extern "C" int i2i_igemm_gn_parts(const i2i_igemm_params* pp, int dtype, int gro
     if (p.zcount < 1) p.zcount = 1;
     // mirrors the routing of i2i_igemm: halo conv when eligible and not forced elsewhere, else the LDS-DMA igemm
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return i2i::conv3x3_w32_gn_parts(p, dtype, groups);
-    if ((p.tile >= 60 && p.tile <= 69 && i2i::conv_narrow_out_eligible(p, dtype)) || (p.tile == 0 && i2i::conv_narrow_out_auto(p, dtype))) return 0;
     const bool halo_ok = p.tile == 0 || (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if (halo_ok && i2i::conv3x3_halo_eligible(p, dtype)) return i2i::conv3x3_halo_gn_parts(p, dtype, groups);
     if ((p.tile >= 60 && p.tile <= 69) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return i2i::conv_narrow_gn_parts(p, dtype, groups);
@@ -387,7 +379,6 @@ extern "C" const char* i2i_igemm_route(const i2i_igemm_params* pp, int dtype) {
     if (p.zcount < 1) p.zcount = 1;
     if (p.zh_count < 1) p.zh_count = 1;
     if ((p.tile >= 40 && p.tile <= 49) || (p.tile == 0 && i2i::conv3x3_w32_auto(p, dtype))) return p.subpix ? "conv3x3_w32_kernel<SUBPIX>" : "conv3x3_w32_kernel";
-    if ((p.tile >= 60 && p.tile <= 69 && i2i::conv_narrow_out_eligible(p, dtype)) || (p.tile == 0 && i2i::conv_narrow_out_auto(p, dtype))) return "conv_narrow_out_kernel";
     const bool halo_forced = (p.tile >= 10 && p.tile <= 19) || (p.tile >= 30 && p.tile <= 39);
     if ((p.tile == 0 || halo_forced) && i2i::conv3x3_halo_eligible(p, dtype)) return p.subpix ? "conv3x3_halo_kernel<SUBPIX>" : "conv3x3_halo_kernel";
     if ((p.tile >= 60 && p.tile <= 69 && i2i::conv_narrow_eligible(p, dtype)) || (p.tile == 0 && i2i::conv_narrow_auto(p, dtype))) return "conv_narrow_kernel";

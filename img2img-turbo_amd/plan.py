@@ -304,9 +304,12 @@ class ForwardPlan:
         un-sliced K loop costs one memory latency per three steps (measured at batch 1, profiles/r6g_*: 256 rows x K = 1280 un-sliced
         17.0 us against 15.5 us sliced + reduced, K = 5120 45 against 24; 1024 rows x K = 640 13.4 against 16.0).
         I2I_SMALL_TILE_ROWS / _K = row / K limits (0 rows = off)."""
-        if self.dtype == torch.float32 or M > self.small_tile_rows or Kd % 64 or Kd > self.small_tile_k or N % 8:
-            return False
-        return -(-M // 64) * -(-N // 32) >= self.small_tile_min_tiles
+        if self.dtype == torch.float32 or M > self.small_tile_rows or Kd % 64 or N % 8 or -(-M // 64) * -(-N // 32) < self.small_tile_min_tiles:
+            return 0
+        # (longer K loops stay K-sliced: the same tile behind an EIGHT-stage ring, 96 KiB, ran 256 rows x K = 1280 in 18.6 us against 15.5
+        # sliced + reduced and 17.0 on the 3-stage ring, +0.35 ms per batch-1 step: profiles/r6i_ab_bs1_small_tile_8_stage_ring_negative.log --
+        # a lone workgroup per CU serialises wait -> barrier -> issue -> read -> MFMA per step whatever the ring holds)
+        return 26 if Kd <= self.small_tile_k else 0
 
     @staticmethod
     def _w32_splitk_cfg(M, N, Kd, min_wgs=96):
@@ -423,7 +426,7 @@ class ForwardPlan:
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         if (ks == 1 and stride == 1 and not ups and not (halo or fused or geglu or out_f32) and force_tile in (0, 20)
                 and self._small_tile(M, N, Kd)):
-            tile_was, force_tile = force_tile, 26
+            tile_was, force_tile = force_tile, self._small_tile(M, N, Kd)
         splitk, ws = (0, None) if (halo or fused or geglu or force_tile == 26) else self._splitk(M, N, Kd)
         mk = lambda tile_, splitk_, ws_: O.conv(
             x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
@@ -518,8 +521,9 @@ class ForwardPlan:
         # with a handful of tiles: +0.06 ... +0.32 ms at batch 1 for row limits 64 ... 4096, neutral at batch 8; profiles/r6d_ab_bs1_unsplit.log.
         # What does pay is the un-sliced launch on tiles small enough to fill the chip: _small_tile)
         op = None
-        if not geglu and self._small_tile(rows, pw["n"], cin):
-            op = mk(26, 0, None)
+        st = 0 if geglu else self._small_tile(rows, pw["n"], cin)
+        if st:
+            op = mk(st, 0, None)
             if self.lib.igemm_route(op[1], self.dt) != "igemm_dma_kernel":
                 op = None
         if op is None:

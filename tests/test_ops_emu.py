@@ -164,14 +164,6 @@ def test_dma_igemm_geglu_bgemm(emu_lib, dtype):
     oc.check_bgemm(emu_lib, "cpu", dtype, out_f32=0, tile=22)
 
 
-def test_conv_narrow_output(emu_lib):
-    """conv_narrow_out_kernel (VAE decoder conv_out: 128 -> 3 with GroupNorm + SiLU applied on the way in): ragged strips (w % 32),
-    segments of 8 rows with a ragged last step (h % 4), 4 output channels, no norm, both 16-bit types."""
-    oc.check_conv(emu_lib, "cpu", torch.bfloat16, n=2, cin=128, cout=3, h=20, w=40, gn=True, act=1, groups=32, tile=60)
-    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=4, h=9, w=33, tile=60, alpha=0.7)
-    oc.check_conv(emu_lib, "cpu", torch.float16, n=1, cin=128, cout=1, h=6, w=8, gn=True, act=0, groups=8, bias=False, tile=60)
-
-
 def test_dma_igemm_small_tile(emu_lib):
     """Tile 26 (64 x 32, four waves along the rows): the batch-1 linears without K slices -- ragged rows / columns, residual, the
     two-source 1x1 (conv_shortcut of a concat), a K tail, fp32."""

@@ -43,7 +43,7 @@ def test_subpixel_and_partials_waits(async_lib):
 @pytest.mark.parametrize("wgs", [0, 1, 3])
 def test_dma_igemm_waits(async_lib, wgs, monkeypatch):
     monkeypatch.setenv("I2I_PERSIST_WGS", str(wgs))
-    for cfg in (22, 23, 24, 25):
+    for cfg in (22, 23, 24, 25, 26):
         oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=320, cout=200, h=12, w=23, ks=1, pad=0, res=True, tile=cfg)      # 5 K steps, ragged
         oc.check_conv(async_lib, "cpu", torch.float16, n=2, cin=64, cout=136, h=16, w=16, ks=1, pad=0, tile=cfg)                 # 1 K step, exact tiles
     oc.check_conv(async_lib, "cpu", torch.bfloat16, n=2, cin=64, cout=72, h=12, w=10, stride=2, pad=1, tile=20)

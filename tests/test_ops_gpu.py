@@ -367,13 +367,3 @@ def test_narrow_input_conv(gpu_lib, dtype):
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=3, cout=128, h=128, w=128, groups=32, tile=0, res=False)
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=3, cout=128, h=44, w=72, groups=32, tile=60, res=False, seed=5)
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_narrow_output_conv(gpu_lib, dtype):
-    """conv_narrow_out_kernel: the VAE decoder's conv_out (128 -> 3 at full resolution, GroupNorm + SiLU applied on the way in) as a
-    read-bound kernel of its own; auto route (tile 0) on a plane of at least 256 workgroups, forced (tile 60) on ragged ones."""
-    oc.check_conv(gpu_lib, "cuda", dtype, n=2, cin=128, cout=3, h=256, w=256, gn=True, act=1, groups=32, tile=0)
-    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cout=3, h=512, w=512, gn=True, act=1, groups=32, tile=0, seed=2)
-    oc.check_conv(gpu_lib, "cuda", dtype, n=1, cin=128, cout=4, h=50, w=72, tile=60, bias=False, seed=3)
-    oc.check_conv(gpu_lib, "cuda", dtype, n=3, cin=128, cout=3, h=37, w=95, gn=True, act=1, groups=32, tile=60, alpha=0.5, seed=4)
