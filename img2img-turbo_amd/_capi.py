@@ -19,7 +19,7 @@ OP_RESIZE_U8 = 13
 OP_NOP = 14
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
-ABI_VERSION = 9          # include/i2i_turbo.h I2I_ABI_VERSION this binding was written for
+ABI_VERSION = 10         # include/i2i_turbo.h I2I_ABI_VERSION this binding was written for
 
 
 class IgemmParams(C.Structure):
@@ -45,7 +45,7 @@ class GnStatsParams(C.Structure):
 
 class GnApplyParams(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("ss", vp), ("nimg", i32), ("hw", i32), ("c", i32), ("act", i32),
-                ("ldx", i32), ("ldy", i32), ("ss_ld", i32), ("ss_off", i32)]
+                ("ldx", i32), ("ldy", i32), ("ss_ld", i32), ("ss_off", i32), ("x1", vp), ("c1", i32), ("ldx1", i32)]
 
 
 class LayerNormParams(C.Structure):

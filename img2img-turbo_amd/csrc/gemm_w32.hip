@@ -786,13 +786,10 @@ int g32_cfg(const i2i_igemm_params& p) {
     if (p.tile >= 51 && p.tile <= 56) return p.tile;
     const bool w160 = p.N % 160 == 0, w128 = p.N % 128 == 0;
     if (p.geglu && w160 && p.K < 1280) return 55;
-    // (A/B hook, I2I_G32_SHORTK = K limit: the plain short-K projections on the two-workgroups-per-CU form as well)
-    const char* e_sk = getenv("I2I_G32_SHORTK");          // (read per call: an A/B process changes it between plans)
-    const int shortk = e_sk ? atoi(e_sk) : 0;
-    if (shortk > 0 && !p.geglu && p.ks == 1 && p.splitk <= 1 && !p.gn_part && p.K <= shortk) {
-        if (w160 && g32_tiles(p, 55) >= 512) return 55;
-        if (w128 && g32_tiles(p, 56) >= 512) return 56;
-    }
+    // (round 6, measured: the plain short-K projections -- to_out, proj_in / proj_out, to_q: K = 320 / 640 -- on the same two-workgroups-per-CU
+    // form: -0.06 ... -0.13 +- 0.07 ms per step, per-op times unchanged (20.4 vs 20.7 us for 32768 x 320 x 320).  They are not tile-bound: 63 MB
+    // of operand + residual + output per 6.7 GFLOP is 3.1 TB/s, i.e. these launches sit on the HBM roofline, not the MFMA one:
+    // profiles/r6j_ab_bs8_g32_shortk.log)
     const int tall = w160 ? 51 : 53;
     if (g32_tiles(p, tall) >= 256) return tall;
     auto fill = [&](int cfg) { const long t = g32_tiles(p, cfg); return (double)t / (double)(((t + 255) / 256) * 256); };

@@ -239,15 +239,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const i2i_gn_apply_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
     constexpr int EPC = Elem<T>::EPC;
-    const int64_t nchunk = (int64_t)p.nimg * p.hw * p.c / EPC;
-    const int cpp = p.c / EPC;   // chunks per pixel
-    const int ldx = p.ldx ? p.ldx : p.c, ldy = p.ldy ? p.ldy : p.c;
-    const int ss_ld = p.ss_ld ? p.ss_ld : p.c;
+    const int c1 = p.x1 ? p.c1 : 0, ct = p.c + c1;      // (a second source: its channels follow the first's in y and ss)
+    const int64_t nchunk = (int64_t)p.nimg * p.hw * ct / EPC;
+    const int cpp = ct / EPC;   // chunks per pixel
+    const int ldx = p.ldx ? p.ldx : p.c, ldx1 = p.ldx1 ? p.ldx1 : c1, ldy = p.ldy ? p.ldy : ct;
+    const int ss_ld = p.ss_ld ? p.ss_ld : ct;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / cpp;
         const int c = (int)(i - pix * cpp) * EPC;
         const int img = (int)(pix / p.hw);
-        chunk_t v = *(const chunk_t*)((const T*)p.x + pix * ldx + c);
+        chunk_t v = c < p.c ? *(const chunk_t*)((const T*)p.x + pix * ldx + c) : *(const chunk_t*)((const T*)p.x1 + pix * ldx1 + (c - p.c));
         const float* ss = p.ss + ((int64_t)img * ss_ld + p.ss_off + c) * 2;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -676,7 +677,8 @@ extern "C" int i2i_gn_stats(const i2i_gn_stats_params* p, int dtype, void* strea
 extern "C" int i2i_gn_apply(const i2i_gn_apply_params* p, int dtype, void* stream) {
     if (!p || !p->x || !p->y || !p->ss) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: null pointer");
     if (p->c % 8 || p->ldx % 8 || p->ldy % 8 || p->ss_off % 4 || ((uintptr_t)p->y & 15)) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: c / ld / offsets must keep 16-byte chunks aligned");
-    const int64_t n = (int64_t)p->nimg * p->hw * p->c / 8;
+    if (p->x1 && (p->c1 < 8 || p->c1 % 8 || p->ldx1 % 8 || ((uintptr_t)p->x1 & 15))) return i2i::fail(I2I_ERR_BAD_ARG, "gn_apply: the second source needs c1 / ldx1 multiples of 8 and a 16-byte aligned base");
+    const int64_t n = (int64_t)p->nimg * p->hw * (p->c + (p->x1 ? p->c1 : 0)) / 8;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {

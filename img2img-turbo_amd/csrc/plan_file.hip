@@ -67,7 +67,7 @@ const std::vector<size_t>& ptr_fields(int opcode) {
                                               PF(igemm, ws), PF(igemm, gn_part), PF(igemm, k2_a), PF(igemm, k2_b), PF(igemm, ln_cs), PF(igemm, c2)};
     static const std::vector<size_t> gn_stats = {PF(gn_stats, x0), PF(gn_stats, x1), PF(gn_stats, gamma), PF(gn_stats, beta), PF(gn_stats, partial),
                                                  PF(gn_stats, ss), PF(gn_stats, counters)};
-    static const std::vector<size_t> gn_apply = {PF(gn_apply, x), PF(gn_apply, y), PF(gn_apply, ss)};
+    static const std::vector<size_t> gn_apply = {PF(gn_apply, x), PF(gn_apply, y), PF(gn_apply, ss), PF(gn_apply, x1)};
     static const std::vector<size_t> layernorm = {PF(layernorm, x), PF(layernorm, y), PF(layernorm, gamma), PF(layernorm, beta)};
     static const std::vector<size_t> softmax = {PF(softmax, s), PF(softmax, p)};
     static const std::vector<size_t> attention = {PF(attention, q), PF(attention, k), PF(attention, vt), PF(attention, o), PF(attention, ws)};

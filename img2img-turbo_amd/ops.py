@@ -93,13 +93,15 @@ def gn_stats(x0, gamma, beta, partial, ss, *, nimg, hw, groups, eps, nparts, x1=
     return K.OP_GN_STATS, _keep(p, x0, x1, gamma, beta, partial, ss, counters)
 
 
-def gn_apply(x, y, ss, *, nimg, hw, c, act, ldx=0, ldy=0, ss_ld=0, ss_off=0, y_off=0):
-    """y[..., y_off:y_off+c] = act(x * scale + shift); ``y_off``/``ldy`` write a channel slice of a wider buffer."""
+def gn_apply(x, y, ss, *, nimg, hw, c, act, ldx=0, ldy=0, ss_ld=0, ss_off=0, y_off=0, x1=None, c1=0, ldx1=0):
+    """y[..., y_off:y_off+c] = act(x * scale + shift); ``y_off``/``ldy`` write a channel slice of a wider buffer.  ``x1`` / ``c1``: a second
+    source whose channels follow x's (the concatenated input of an up-block resnet in one launch)."""
     p = K.GnApplyParams()
     p.x, p.ss, p.nimg, p.hw, p.c, p.act = ptr(x), ptr(ss), nimg, hw, c, act
     p.y = ptr(y) + y_off * y.element_size()
     p.ldx, p.ldy, p.ss_ld, p.ss_off = ldx, ldy, ss_ld, ss_off
-    return K.OP_GN_APPLY, p
+    p.x1, p.c1, p.ldx1 = ptr(x1), (c1 if x1 is not None else 0), ldx1
+    return K.OP_GN_APPLY, _keep(p, x, y, ss, x1)
 
 
 def layernorm(x, y, gamma, beta, *, rows, c, eps=1e-5, ldx=None, ldy=None):

@@ -133,6 +133,7 @@ class ForwardPlan:
         self.small_tile_rows = int(os.environ.get("I2I_SMALL_TILE_ROWS", "4096"))   # see _small_tile (A/B hooks)
         self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
         self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
+        self.gn_apply_one = os.environ.get("I2I_GN_APPLY_ONE", "1") != "0"
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
@@ -417,12 +418,16 @@ class ForwardPlan:
             # planes / 1x1 projections have no operand prologue, and the extra pass is over a few MB at most
             ct = x.c + c1
             y = self.new(x.n, x.h, x.w, ct)
-            for src, coff in ((x, 0), (x1, x.c)):
-                if src is None:
-                    continue
-                op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+            # (ABI v10: both sources of a concatenated input in ONE launch; I2I_GN_APPLY_ONE=0 keeps one per source: A/B hook)
+            if x1 is not None and not self.gn_apply_one:
+                for src, coff in ((x, 0), (x1, x.c)):
+                    op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
+                    self._pending_gn.append((op[1], "apply"))
+                    self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
+            else:
+                op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act, ldy=ct, ss_ld=ct, x1=x1.t if x1 else None, c1=c1)
                 self._pending_gn.append((op[1], "apply"))
-                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
+                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * ct * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         if (ks == 1 and stride == 1 and not ups and not (halo or fused or geglu or out_f32) and force_tile in (0, 20)
                 and self._small_tile(M, N, Kd)):

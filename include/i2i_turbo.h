@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define I2I_ABI_VERSION 9
+#define I2I_ABI_VERSION 10
 
 typedef enum { I2I_F32 = 0, I2I_BF16 = 1, I2I_F16 = 2,
                I2I_U8 = 3   /* only as src_dtype / dst_dtype of the boundary layout ops: uint8 images, HWC interleaved */
@@ -89,7 +89,7 @@ typedef struct {
     int32_t geglu;             /* 1: B rows interleaved [a16|g16]; out[:, n/2] = a * gelu(g); ldc for N/2 */
     int32_t out_f32;           /* 1: store fp32 regardless of dtype (attention scores) */
     int32_t tile;              /* 0 = auto; else forces a kernel / tile config id (tests / tuning):
-                                  1-5 register-staged igemm, 10-19 / 30-39 halo conv3x3, 20-25 LDS-DMA igemm,
+                                  1-5 register-staged igemm, 10-19 / 30-39 halo conv3x3, 20-26 LDS-DMA igemm (26: 64x32 tiles),
                                   40-49 wide-tile conv3x3 (32x32x16 MFMA, conv3x3_w32.hip; 40 = its own auto; with `subpix` its
                                   sub-pixel upsampler form), 50-56 wide GEMM (32x32x16 MFMA, gemm_w32.hip; 50 = its own auto,
                                   51 256x160, 52 128x160, 53 256x128, 54 128x128 workgroup tiles; 55 / 56 = 52 / 54 with a 2-deep
@@ -162,6 +162,10 @@ typedef struct {
     const void* x; void* y; const float* ss; int32_t nimg, hw, c, act;
     int32_t ldx, ldy;          /* pixel strides in elements (0 = c): y may be a channel slice of a concat buffer */
     int32_t ss_ld, ss_off;     /* ss is [nimg][ss_ld][2]; this tensor's channels start at ss_off (0,0 = c,0) */
+    const void* x1;            /* ABI v10: optional SECOND source [nimg*hw][ldx1] of c1 channels (torch.cat([x, x1], 1) in front of the norm:
+                                  the resnets of the UNet's up blocks): its channels follow x's in y and in ss -- one launch normalises the
+                                  concatenated input (it was one launch per source) */
+    int32_t c1, ldx1;          /* c1 multiple of 8; ldx1 = 0 means c1 */
 } i2i_gn_apply_params;
 
 /* LayerNorm over the last dim (F.layer_norm, eps 1e-5, affine). rows x c, c multiple of 8. */
@@ -176,7 +180,11 @@ typedef struct {
 } i2i_softmax_params;
 
 /* Fused flash-style attention (F.scaled_dot_product_attention, no mask, not causal).
- * q [b][tq][ldq] / k [b][tk][ldk] with head h at column h*d; vt is V^T: [b][heads*d][ldvt] (tk contiguous). */
+ * q [b][tq][ldq] / k [b][tk][ldk] with head h at column h*d; vt is V^T: [b][heads*d][ldvt] (tk contiguous).
+ * o = softmax(scale * q k^T) v.  The 16-bit d = 64 kernel works in log2 units: it multiplies q by scale * log2(e) once at load (one
+ * more rounding of q to the 16-bit type) UNLESS scale * log2(e) == 1, i.e. the caller passes q already multiplied by the factor and
+ * scale = ln 2 -- the same function, and what the model's planner does (the factor is folded into to_q's weights before they are
+ * rounded: Packer out_scale / scale0). */
 typedef struct {
     const void* q; const void* k; const void* vt; void* o;
     int32_t batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo;

@@ -284,6 +284,28 @@ def check_softmax(lib, device, dtype, *, rows=11, cols=77, ldp=80, seed=0):
     return err
 
 
+def check_gn_apply(lib, device, dtype, *, n=2, c=64, c1=0, h=6, w=7, act=1, seed=0):
+    """Standalone GroupNorm apply (+SiLU) from a (scale, shift) table; ``c1``: a second source whose channels follow the first's
+    (i2i_gn_apply_params.x1, ABI v10: the concatenated input of an up-block resnet in one launch)."""
+    g = torch.Generator().manual_seed(seed)
+    ct = c + c1
+    x = torch.randn(n, h * w, ct, generator=g).to(dtype)
+    ss = torch.stack([1 + 0.2 * torch.randn(n, ct, generator=g), 0.3 * torch.randn(n, ct, generator=g)], -1).contiguous()
+    ref = x.float() * ss[:, None, :, 0] + ss[:, None, :, 1]
+    if act:
+        ref = F.silu(ref)
+    x0 = x[..., :c].contiguous().to(device)
+    x1 = x[..., c:].contiguous().to(device) if c1 else None
+    y = torch.full((n, h * w, ct), float("nan"), dtype=dtype, device=device)
+    opcode, p = O.gn_apply(x0, y, ss.to(device), nimg=n, hw=h * w, c=c, act=act, ldy=ct, ss_ld=ct, x1=x1, c1=c1)
+    run_op(lib, opcode, p, dtype, device)
+    got = y.cpu().float()
+    assert torch.isfinite(got).all()
+    err = rel_err(got, ref)
+    assert err < TOL[dtype], f"gn_apply rel err {err}"
+    return err
+
+
 def check_attention(lib, device, dtype, *, batch=2, heads=2, tq=70, tk=77, d=64, seed=0, spike=False, ksplit=0):
     """ksplit > 1: keys divided among ksplit workgroups per query tile + the merge launch (i2i_attention_params.ksplit, d = 512)."""
     g = torch.Generator().manual_seed(seed)

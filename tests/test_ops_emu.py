@@ -237,6 +237,13 @@ def test_subpixel_weights_identity():
     assert (out - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_gn_apply_one_and_two_sources(emu_lib, dtype):
+    oc.check_gn_apply(emu_lib, "cpu", dtype, n=2, c=64, h=6, w=7)
+    oc.check_gn_apply(emu_lib, "cpu", dtype, n=2, c=64, c1=24, h=5, w=9, seed=1)        # torch.cat([x, skip], 1) in front of the norm
+    oc.check_gn_apply(emu_lib, "cpu", dtype, n=1, c=8, c1=128, h=3, w=3, act=0, seed=2)
+
+
 def test_gn_stats_single_launch_shapes(emu_lib):
     """gn_stats_small_kernel: channel ranges of a block that straddle the concat seam, cpg not a multiple of 8."""
     oc.check_gn_stats(emu_lib, "cpu", torch.bfloat16, c0=640, c1=320, groups=32, h=4, w=4, nparts=1, n=2)    # cpg 30, seam inside a block

@@ -367,3 +367,9 @@ def test_narrow_input_conv(gpu_lib, dtype):
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=2, cin=3, cout=128, h=128, w=128, groups=32, tile=0, res=False)
     oc.check_conv_gn_part(gpu_lib, "cuda", dtype, n=1, cin=3, cout=128, h=44, w=72, groups=32, tile=60, res=False, seed=5)
 
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gn_apply_one_and_two_sources(gpu_lib, dtype):
+    oc.check_gn_apply(gpu_lib, "cuda", dtype, n=2, c=320, h=64, w=64)
+    oc.check_gn_apply(gpu_lib, "cuda", dtype, n=2, c=1280, c1=640, h=32, w=32, seed=1)     # up-block resnet input
+    oc.check_gn_apply(gpu_lib, "cuda", dtype, n=1, c=320, c1=320, h=63, w=65, act=0, seed=2)
