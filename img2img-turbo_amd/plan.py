@@ -130,8 +130,11 @@ class ForwardPlan:
         # with a tiny model)
         self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
         self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
+        self.w32_splitk_longk = int(os.environ.get("I2I_W32_SPLITK_LONGK", "32"))
+        self.w32_splitk_longk_sk = int(os.environ.get("I2I_W32_SPLITK_LONGK_SK", "2"))
         self.small_tile_rows = int(os.environ.get("I2I_SMALL_TILE_ROWS", "4096"))   # see _small_tile (A/B hooks)
         self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
+        self.small_tile_k2 = int(os.environ.get("I2I_SMALL_TILE_K2", "1280"))      # K limit when the tiles are >= 512 (two or more per CU)
         self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
         self.gn_apply_one = os.environ.get("I2I_GN_APPLY_ONE", "1") != "0"
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
@@ -310,10 +313,10 @@ class ForwardPlan:
         # (longer K loops stay K-sliced: the same tile behind an EIGHT-stage ring, 96 KiB, ran 256 rows x K = 1280 in 18.6 us against 15.5
         # sliced + reduced and 17.0 on the 3-stage ring, +0.35 ms per batch-1 step: profiles/r6i_ab_bs1_small_tile_8_stage_ring_negative.log --
         # a lone workgroup per CU serialises wait -> barrier -> issue -> read -> MFMA per step whatever the ring holds)
-        return 26 if Kd <= self.small_tile_k else 0
+        return 26 if (Kd <= self.small_tile_k or (Kd <= self.small_tile_k2 and -(-M // 64) * -(-N // 32) >= 512)) else 0
 
     @staticmethod
-    def _w32_splitk_cfg(M, N, Kd, min_wgs=96):
+    def _w32_splitk_cfg(M, N, Kd, min_wgs=96, longk=32, longk_sk=2):
         """(wide-GEMM tile id, K slices) for a small-plane 3x3 convolution; (0, 0) = leave it on the LDS-DMA igemm.
         Measured at batch 8 (profiles/r4h_bench_ops_splitk_w32.log vs _dma.log): 512 rows -> 128 x 128 tiles x 6 slices
         (1280 -> 1280 @ 8 x 8: 0.050 -> 0.034 ms), 2048 rows -> 256 x 160 x 4 when that gives 64 tiles (1280 -> 1280 @ 16 x 16:
@@ -331,6 +334,10 @@ class ForwardPlan:
         bm, bn = {51: (256, 160), 52: (128, 160), 54: (128, 128)}[cfg]
         tiles = -(-M // bm) * -(-N // bn)
         sk = 1 if tiles >= 128 else max(1, min(256 // tiles, stages // 8))      # (half a round of tiles beats slicing a short K)
+        if 128 <= tiles < 256 and stages >= longk:
+            # ... but not a long one: the VAE's 64 x 64-plane 512 -> 512 convolutions of a batch-1 forward (128 tiles x 72 stages) in two
+            # slices: 50 -> 39 us each, -0.14 +- 0.01 ms per batch-1 step (profiles/r6l_ab_bs1_w32_longk_two_slices.log; I2I_W32_SPLITK_LONGK)
+            sk = longk_sk
         if tiles * sk < min_wgs:
             return 0, 0
         return cfg, sk
@@ -399,7 +406,7 @@ class ForwardPlan:
             # These two groups leave a conv the halo kernel would take (with GroupNorm fused into its staging) for a wide-GEMM
             # route that needs the norm materialised: ask the C dispatcher about exactly that op BEFORE recording the extra
             # gn_apply pass, and keep the halo decision when it says no (wide_ok restates only part of gemm_w32_eligible).
-            cfg_, sk_ = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs)
+            cfg_, sk_ = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk, self.w32_splitk_longk_sk)
             ok_ = bool(cfg_) and M >= self.w32_splitk_min_rows and x.c % epc == 0 and c1 % epc == 0
             if ok_:
                 ct_ = x.c + c1
@@ -433,6 +440,9 @@ class ForwardPlan:
                 and self._small_tile(M, N, Kd)):
             tile_was, force_tile = force_tile, self._small_tile(M, N, Kd)
         splitk, ws = (0, None) if (halo or fused or geglu or force_tile == 26) else self._splitk(M, N, Kd)
+        # (round 6, measured negative: the 256-row weight-streaming 3x3 convs of a batch-1 forward on ONE 256-row tile per column block
+        # (tile 25) instead of four 64-row tiles that each stream the same weight slab: 50 -> 52.6 / 33 -> 36.7 us, +0.09 ms per step;
+        # more than two slices for the 128-tile long-K wide-GEMM convs: +0.18 ... +0.26 ms: profiles/r6m_ab_bs1_*.log)
         mk = lambda tile_, splitk_, ws_: O.conv(
             x_in0.t, pw["w"], out.t, nimg=x.n, hin=hin, win=win, ho=ho, wo=wo, ks=ks, stride=stride, pad=pad, ups=ups,
             x1=x_in1.t if x_in1 else None, c0=c0_eff, c1=c1_eff, lda0=c0_eff, lda1=c1_eff, N=pw["n"],
@@ -445,7 +455,7 @@ class ForwardPlan:
                 and x_in1 is None and M >= self.w32_splitk_min_rows):
             # UNet small-plane / stride-2 3x3 convolutions on the wide GEMM (csrc/gemm_w32.hip: im2col gather + K slices): the tile
             # and slice count that put ~256 workgroups on the chip with >= 8 stages each (sweep: profiles/r4h_bench_ops_splitk_*)
-            cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs)
+            cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk, self.w32_splitk_longk_sk)
             if cfg:
                 ws2 = self.pool.get(sk * M * N, torch.float32) if sk > 1 else None
                 cand = mk(cfg, sk if sk > 1 else 0, ws2)
