@@ -16,7 +16,9 @@ F=$(find $O/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find $O
 python tools/pmc_traffic.py $F $W conv3x3_ --batch 8 --dtype bf16 --size 512 --source-hash $(python -c "import bench; print(bench.source_hash())") \
     --collected "$TAG: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '$CMD'" > $O/${TAG}_traffic_conv3x3.json
 cp $O/${TAG}_traffic_conv3x3.json profiles/traffic_conv3x3.json
+t0=$SECONDS
 python bench.py --per-op $O/${TAG}_per_op_bs8.txt > $O/${TAG}_bench_bs8.json 2> $O/${TAG}_bench_bs8.err
+echo "default bench.py line (what the driver runs): $((SECONDS - t0)) s of wall clock"
 # the same step with every VAE resnet's conv2 bias + 30 (residual streams on DC offsets: GroupNorm groups take the second pass)
 python bench.py --activation-offset 30 --no-cpu-baseline --no-f32 --no-latency --steps 20 > $O/${TAG}_bench_bs8_offset30.json 2>> $O/${TAG}_bench_bs8.err
 python bench.py --activation-offset 30 --dtype f16 --steps 20 --no-f32 --no-latency > $O/${TAG}_bench_bs8_offset30_f16.json 2>> $O/${TAG}_bench_bs8.err
