@@ -131,12 +131,10 @@ class ForwardPlan:
         self.w32_splitk_min_rows = int(os.environ.get("I2I_W32_SPLITK_MIN_ROWS", "512"))
         self.w32_splitk_min_wgs = int(os.environ.get("I2I_W32_SPLITK_MIN_WGS", "96"))
         self.w32_splitk_longk = int(os.environ.get("I2I_W32_SPLITK_LONGK", "32"))
-        self.w32_splitk_longk_sk = int(os.environ.get("I2I_W32_SPLITK_LONGK_SK", "2"))
         self.small_tile_rows = int(os.environ.get("I2I_SMALL_TILE_ROWS", "4096"))   # see _small_tile (A/B hooks)
         self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
         self.small_tile_k2 = int(os.environ.get("I2I_SMALL_TILE_K2", "1280"))      # K limit when the tiles are >= 512 (two or more per CU)
         self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
-        self.gn_apply_one = os.environ.get("I2I_GN_APPLY_ONE", "1") != "0"
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
@@ -316,7 +314,7 @@ class ForwardPlan:
         return 26 if (Kd <= self.small_tile_k or (Kd <= self.small_tile_k2 and -(-M // 64) * -(-N // 32) >= 512)) else 0
 
     @staticmethod
-    def _w32_splitk_cfg(M, N, Kd, min_wgs=96, longk=32, longk_sk=2):
+    def _w32_splitk_cfg(M, N, Kd, min_wgs=96, longk=32):
         """(wide-GEMM tile id, K slices) for a small-plane 3x3 convolution; (0, 0) = leave it on the LDS-DMA igemm.
         Measured at batch 8 (profiles/r4h_bench_ops_splitk_w32.log vs _dma.log): 512 rows -> 128 x 128 tiles x 6 slices
         (1280 -> 1280 @ 8 x 8: 0.050 -> 0.034 ms), 2048 rows -> 256 x 160 x 4 when that gives 64 tiles (1280 -> 1280 @ 16 x 16:
@@ -337,7 +335,7 @@ class ForwardPlan:
         if 128 <= tiles < 256 and stages >= longk:
             # ... but not a long one: the VAE's 64 x 64-plane 512 -> 512 convolutions of a batch-1 forward (128 tiles x 72 stages) in two
             # slices: 50 -> 39 us each, -0.14 +- 0.01 ms per batch-1 step (profiles/r6l_ab_bs1_w32_longk_two_slices.log; I2I_W32_SPLITK_LONGK)
-            sk = longk_sk
+            sk = 2          # (3 / 4 slices measured worse: +0.26 / +0.18 ms, profiles/r6m_ab_bs1_*.log)
         if tiles * sk < min_wgs:
             return 0, 0
         return cfg, sk
@@ -406,7 +404,7 @@ class ForwardPlan:
             # These two groups leave a conv the halo kernel would take (with GroupNorm fused into its staging) for a wide-GEMM
             # route that needs the norm materialised: ask the C dispatcher about exactly that op BEFORE recording the extra
             # gn_apply pass, and keep the halo decision when it says no (wide_ok restates only part of gemm_w32_eligible).
-            cfg_, sk_ = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk, self.w32_splitk_longk_sk)
+            cfg_, sk_ = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk)
             ok_ = bool(cfg_) and M >= self.w32_splitk_min_rows and x.c % epc == 0 and c1 % epc == 0
             if ok_:
                 ct_ = x.c + c1
@@ -425,16 +423,11 @@ class ForwardPlan:
             # planes / 1x1 projections have no operand prologue, and the extra pass is over a few MB at most
             ct = x.c + c1
             y = self.new(x.n, x.h, x.w, ct)
-            # (ABI v10: both sources of a concatenated input in ONE launch; I2I_GN_APPLY_ONE=0 keeps one per source: A/B hook)
-            if x1 is not None and not self.gn_apply_one:
-                for src, coff in ((x, 0), (x1, x.c)):
-                    op = O.gn_apply(src.t, y.t, None, nimg=x.n, hw=x.hw, c=src.c, act=act, ldy=ct, ss_ld=ct, ss_off=coff, y_off=coff)
-                    self._pending_gn.append((op[1], "apply"))
-                    self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * src.c * self.esz)
-            else:
-                op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act, ldy=ct, ss_ld=ct, x1=x1.t if x1 else None, c1=c1)
-                self._pending_gn.append((op[1], "apply"))
-                self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * ct * self.esz)
+            # (ABI v10: both sources of a concatenated input in ONE launch -- it was one per source: -0.06 +- 0.05 ms per batch-8 step,
+            # -0.04 +- 0.015 ms at batch 1, profiles/r6k_ab_*_gn_apply_one.log)
+            op = O.gn_apply(x.t, y.t, None, nimg=x.n, hw=x.hw, c=x.c, act=act, ldy=ct, ss_ld=ct, x1=x1.t if x1 else None, c1=c1)
+            self._pending_gn.append((op[1], "apply"))
+            self._add(op, label + ".gn_apply", nbytes=2 * x.n * x.hw * ct * self.esz)
             x_in0, x_in1, c0_eff, c1_eff = y, None, ct, 0
         if (ks == 1 and stride == 1 and not ups and not (halo or fused or geglu or out_f32) and force_tile in (0, 20)
                 and self._small_tile(M, N, Kd)):
@@ -455,7 +448,7 @@ class ForwardPlan:
                 and x_in1 is None and M >= self.w32_splitk_min_rows):
             # UNet small-plane / stride-2 3x3 convolutions on the wide GEMM (csrc/gemm_w32.hip: im2col gather + K slices): the tile
             # and slice count that put ~256 workgroups on the chip with >= 8 stages each (sweep: profiles/r4h_bench_ops_splitk_*)
-            cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk, self.w32_splitk_longk_sk)
+            cfg, sk = self._w32_splitk_cfg(M, N, Kd, self.w32_splitk_min_wgs, self.w32_splitk_longk)
             if cfg:
                 ws2 = self.pool.get(sk * M * N, torch.float32) if sk > 1 else None
                 cand = mk(cfg, sk if sk > 1 else 0, ws2)
