@@ -13,3 +13,8 @@ timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACT
     --output-format csv -d $O/${T}_pmc_att2 -o att -- python benchmarks/bench_attention.py >> $O/${T}_pmc_att.log 2>&1
 python tools/pmc_summary.py $(find $O/${T}_pmc_att1 $O/${T}_pmc_att2 -name "*counter_collection.csv" | sort | tr '\n' ' ') attention_dma > $O/${T}_pmc_attention_summary.txt 2>&1
 cat $O/${T}_pmc_attention_summary.txt
+# gpurun merges at most 64 MiB back: the raw rocprofv3 directories (kernel traces, counter csv files of whole bench runs) stay on the box,
+# their summaries above are what is kept
+find $O -mindepth 1 -maxdepth 1 -type d -name "${T}_*" -exec rm -rf {} +
+find $O -type f -size +3M -delete
+du -sh $O
