@@ -445,8 +445,19 @@ def main():
     # N ranks build and pack ~950 M synthetic parameters on the host at the same time: each gets its share of the cores
     # (unconstrained they oversubscribe each other), and the set-up time is reported per rank next to the timed region.
     t_setup = time.perf_counter()
+    phase, t_phase = {}, [time.perf_counter()]      # wall seconds of every phase of this process, reported as `phase_s` (N = 1)
+
+    def mark(name):
+        now = time.perf_counter()
+        phase[name] = round(phase.get(name, 0.0) + now - t_phase[0], 1)
+        t_phase[0] = now
     if world > 1:
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    elif not emu:
+        # torch sizes its intra-op pool to the HOST's cores (256) before this process confines itself to the GPU's NUMA node (128): the
+        # over-subscribed pool made the host side of packing 3-5x slower (round 6: 68 s per model; the whole default line 330 s).  The
+        # packer's ops are short memory-bound copies: a small fixed pool is the fast setting.
+        torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
     # (N > 1: rank 0 synthesises, the other ranks map the same /dev/shm safetensors file -- dp.shared_weights -- instead of 8 ranks
     # building ~950 M parameters each at the same time)
     def build_weights():
@@ -458,6 +469,7 @@ def main():
         return w_
     weights = dp.shared_weights(build_weights, rank, world, tag="bench")
     t_weights = time.perf_counter() - t_setup
+    mark("weights_synthesis")
     if a.model == "cyclegan":
         model = CycleGAN_Turbo(weights=weights, device=dev, dtype=dtype, **lib_kw)
         kind, cfg = "photo", 3
@@ -474,6 +486,7 @@ def main():
     gather = dp.OutputGather(plan.out, total, overlap=not a.serial_gather) if (world > 1 and not a.no_gather) else None
     torch.cuda.synchronize()
     setup_s = dp.all_ranks(time.perf_counter() - t_setup, dev)
+    mark("pack_upload_plan")
 
     def step():
         plan.replay()
@@ -505,6 +518,7 @@ def main():
         torch.cuda.synchronize()
         ms_compute = [round(v / a.steps * 1e3, 3) for v in dp.all_ranks(time.perf_counter() - t1, dev)]
 
+    mark("warmup_and_timed_region")
     if rank != 0:
         return
     name = {"pix2pix": "pix2pix-turbo sketch_to_image_stochastic gamma=%g" % a.gamma if a.stochastic else "pix2pix-turbo edge_to_image",
@@ -536,11 +550,14 @@ def main():
         rec["roofline"] = roof
         rec["kernel_breakdown_ms"] = breakdown
         rec["sum_kernel_ms"] = round(tot, 3)
+        mark("per_op_event_pass")
         if not a.no_calib:
             rec["calib"] = calibrate(model.lib, dev, breakdown, ms_per_step, B)
             if rec["calib"].get("value_normalised"):
                 rec["value_normalised"] = rec["calib"]["value_normalised"]
+        mark("calib")
         pc = None if a.no_power else power_and_clock(plan)
+        mark("power_poll")
         if pc:
             rec["power"] = pc
             if roof and roof.get("frac") and pc["gfx_mhz"] > 0:
@@ -597,6 +614,7 @@ def main():
                     lat.append((time.perf_counter() - t) * 1e3)
                 rec["latency_bs%d_ms_p50" % lb] = round(statistics.median(lat), 3)
                 rec["latency_bs%d_ms_per_image_p50" % lb] = round(statistics.median(lat) / lb, 3)
+        mark("forward_api_and_latency_plans")
         out32 = None
         mode_out = {}          # image 0 of the batch in the other precision modes (parity against the CPU oracle below)
         if a.dtype != "f32" and not a.no_f32 and a.arch == "sd-turbo":
@@ -639,6 +657,7 @@ def main():
             m32.release_plans()
             del m32, p32
             torch.cuda.empty_cache()
+        mark("f32_mode")
         if a.dtype == "bf16" and not a.no_modes and a.arch == "sd-turbo":
             # the 16-bit precision modes side by side on the SAME batch: throughput + parity of image 0 (filled in below)
             rec["precision_modes"] = {"bf16": {"images_per_s": round(value, 2)}}
@@ -661,8 +680,10 @@ def main():
                 torch.cuda.empty_cache()
             if "images_per_s_f32" in rec:
                 rec["precision_modes"]["f32_exact"] = {"images_per_s": rec["images_per_s_f32"]}
+        mark("precision_modes")
         if not a.no_cpu_baseline:
             cb, ref = cpu_baseline(a, weights, x, cap, eps, noise)
+            mark("cpu_baseline")
             rec["cpu_baseline"] = cb
             d = (out[:1].float().cpu() - ref).abs()
             mse = float((d ** 2).mean())
@@ -683,6 +704,8 @@ def main():
                     pm_["f32_exact"].update(parity_max_abs=rec["parity_max_abs_f32"])
                 pm_["note"] = ("image 0 of the benchmarked batch vs the CPU fp32 oracle; mixed = UNet in fp16 (the network whose error the 1-step scheduler "
                                "multiplies by 14.6) with the VAE in bf16 (whose real activations overflow fp16)")
+    if world == 1:
+        rec["phase_s"] = dict(phase, total=round(sum(phase.values()), 1))
     print(json.dumps(rec), flush=True)
 
 
