@@ -133,7 +133,6 @@ class ForwardPlan:
         self.w32_splitk_longk = int(os.environ.get("I2I_W32_SPLITK_LONGK", "32"))
         self.small_tile_rows = int(os.environ.get("I2I_SMALL_TILE_ROWS", "4096"))   # see _small_tile (A/B hooks)
         self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
-        self.small_tile_k2 = int(os.environ.get("I2I_SMALL_TILE_K2", "1280"))      # K limit when the tiles are >= 512 (two or more per CU)
         self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
         self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
@@ -311,7 +310,9 @@ class ForwardPlan:
         # (longer K loops stay K-sliced: the same tile behind an EIGHT-stage ring, 96 KiB, ran 256 rows x K = 1280 in 18.6 us against 15.5
         # sliced + reduced and 17.0 on the 3-stage ring, +0.35 ms per batch-1 step: profiles/r6i_ab_bs1_small_tile_8_stage_ring_negative.log --
         # a lone workgroup per CU serialises wait -> barrier -> issue -> read -> MFMA per step whatever the ring holds)
-        return 26 if (Kd <= self.small_tile_k or (Kd <= self.small_tile_k2 and -(-M // 64) * -(-N // 32) >= 512)) else 0
+        # (K up to 1280 where the tile gives >= 512 workgroups: -0.02 +- 0.014 ms at batch 1 but +0.26 +- 0.05 ms at batch 8, where it takes
+        # the 2048-row x 1280 x 1280 projections from the wide GEMM: profiles/r6m_*, r6o_ab_bs8_small_tile_rules.log)
+        return 26 if Kd <= self.small_tile_k else 0
 
     @staticmethod
     def _w32_splitk_cfg(M, N, Kd, min_wgs=96, longk=32):
