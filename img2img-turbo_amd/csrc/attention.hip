@@ -237,7 +237,11 @@ __device__ __forceinline__ int att_key_of(int kf, int m) { return 32 * (kf >> 1)
 
 // QF = query fragments per wave: 2 (128 queries per workgroup) for the launches that fill the chip, 1 (64 queries, twice the
 // workgroups) for the small grids of a batch-1 forward, where a workgroup's 64 serial key tiles are the launch.
-template <typename T, int QF>
+// SPLIT (p.ksplit > 1, p.ws; round 6): the key tiles are divided among ksplit workgroups per query tile, as in attention_wide_kernel below --
+// at batch 1 the T = 4096 self-attention is 320 workgroups of 64 SERIAL key tiles, ~1 us each when a wave has its SIMD to itself; a split
+// workgroup runs its share and writes the UNNORMALISED O^T (fp32) with (reference, row sum) of every query to p.ws, attention_combine64_kernel
+// merges the partials.  Not with the causal mask (the text tower's 77 keys are two tiles).
+template <typename T, int QF, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attention_params p) {
     typedef typename Elem<T>::chunk_t chunk_t;
     static_assert(Elem<T>::EPC == 8, "16-bit types only");
@@ -245,14 +249,26 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     constexpr float LAZY = 8.0f;                                              // log2 units a score may exceed its reference by
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    int qt, h, b;
-    if (!att_group_of_block((p.tq + QT - 1) / QT, p.heads, p.batch, qt, h, b)) return;
+    int qt, h, b, ks = 0;
+    if constexpr (!SPLIT) {
+        if (!att_group_of_block((p.tq + QT - 1) / QT, p.heads, p.batch, qt, h, b)) return;
+    } else {
+        int hs;
+        if (!att_group_of_block((p.tq + QT - 1) / QT, p.heads * p.ksplit, p.batch, qt, hs, b)) return;
+        h = hs / p.ksplit;
+        ks = hs - h * p.ksplit;
+    }
     const int q0 = qt * QT + wave * (16 * QF);
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D);
     const char* vp = (const char*)((const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)h * D * p.ldvt);
-    const int ntile = (p.tk + BKV - 1) / BKV;
+    int t_begin = 0, ntile = (p.tk + BKV - 1) / BKV;          // this workgroup's key tiles: t_begin .. ntile - 1
+    if constexpr (SPLIT) {
+        const int per = (ntile + p.ksplit - 1) / p.ksplit;
+        t_begin = ks * per;
+        ntile = t_begin + per < ntile ? t_begin + per : ntile;
+    }
 
     // this wave's DMA pieces: pc = wave*4 + q; pc < 8 (waves 0, 1): K rows pc*8.. (row = key), else V^T rows (pc-8)*8.. (row = d).
     // The lane offsets of tile 0 are computed ONCE; a tile adds a wave-uniform stride to the scalar base (64 keys: 64 rows of K,
@@ -334,14 +350,14 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
         m_ref[f] = 0.f;
     }
 
-    dma_tile(0, 0);
-    if (ntile > 1) dma_tile(1, 1);
-    for (int t = 0; t < ntile; ++t) {
-        const int st = t % 3, kv0 = t * BKV;
+    if (t_begin < ntile) dma_tile(t_begin, 0);
+    if (t_begin + 1 < ntile) dma_tile(t_begin + 1, 1);
+    for (int t = t_begin; t < ntile; ++t) {
+        const int st = (t - t_begin) % 3, kv0 = t * BKV;
         // tile t landed (leave the batch of tile t+1 in flight), everyone is done with tile t-1 -> its slot is free
         if (t + 1 < ntile) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
         lds_barrier();
-        if (t + 2 < ntile) dma_tile(t + 2, (t + 2) % 3);
+        if (t + 2 < ntile) dma_tile(t + 2, (t + 2 - t_begin) % 3);
         const char* Ks = i2i_smem + st * STAGE;
         const char* Vs = Ks + BKV * 128;
         if (kv0 + BKV > p.tk && (p.tk & 7)) {              // last tile, partially valid V^T chunk: clean its tail in LDS
@@ -390,17 +406,17 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
                 for (int r = 0; r < 4; ++r) mt[f] = fmaxf(mt[f], sacc[f][kf][r]);
         }
         // ---- slow path (first tile; some score more than 2^LAZY above its reference): move the references ----
-        if (t == 0 || wave_any(fmaxf(mt[0], mt[QF - 1]) > LAZY)) {
+        if (t == t_begin || wave_any(fmaxf(mt[0], mt[QF - 1]) > LAZY)) {
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 const float m = quad_max(mt[f]);
-                const float m_new = m_ref[f] + (t == 0 ? m : fmaxf(m, 0.f));
+                const float m_new = m_ref[f] + (t == t_begin ? m : fmaxf(m, 0.f));
                 const float dd = m_new - m_ref[f];
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc[f][kf][r] -= dd;
-                if (t > 0) {
+                if (t > t_begin) {
                     const float alpha = exp2_fast(-dd);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) oacc[f][i] *= alpha;
@@ -436,8 +452,24 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const i2i_attenti
     // ---- finalize: every lane holds the row sum of its query; normalise, store 4 consecutive d per lane ----
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        const float inv = 1.0f / lacc[f][0];
         const int qi = q0 + f * 16 + lr;
+        if constexpr (SPLIT) {
+            // partial results: ws = [G][tq][64] fp32 unnormalised O, then [G][tq][2] = (reference in log2 units, row sum); an empty split
+            // (more splits than key tiles) contributes weight 0
+            const int64_t G = (int64_t)p.batch * p.heads * p.ksplit, gq = (((int64_t)b * p.heads + h) * p.ksplit + ks) * p.tq + qi;
+            if (qi < p.tq) {
+                float* wo = (float*)p.ws + gq * D;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(f32x4*)(wo + i * 16 + lq * 4) = oacc[f][i];
+                if (lq == 0) {
+                    float* ml = (float*)p.ws + G * p.tq * D + gq * 2;
+                    ml[0] = t_begin < ntile ? m_ref[f] : -1e30f;
+                    ml[1] = lacc[f][0];
+                }
+            }
+            continue;
+        }
+        const float inv = 1.0f / lacc[f][0];
         if (qi < p.tq) {
             T* op = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D;
             typedef T tx4 __attribute__((ext_vector_type(4)));
@@ -763,12 +795,53 @@ int launch_att_wide(const i2i_attention_params& p, hipStream_t s) {
     return i2i::check_launch("attention_wide");
 }
 
+// Merge of the key-split partials of the d = 64 kernel: 8 lanes per query, a lane owns 8 channels (see attention_combine_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_combine64_kernel(const i2i_attention_params p) {
+    constexpr int D = 64;
+    const int64_t nq = (int64_t)p.batch * p.heads * p.tq, idx = (int64_t)blockIdx.x * 256 + threadIdx.x, q = idx >> 3;
+    const int c8 = (int)(idx & 7) * 8;
+    if (q >= nq) return;
+    const int64_t bh = q / p.tq;
+    const int qi = (int)(q - bh * p.tq), b = (int)(bh / p.heads), h = (int)(bh - (int64_t)b * p.heads);
+    const int S = p.ksplit;
+    const float* part = (const float*)p.ws;
+    const float* ml = part + (int64_t)p.batch * p.heads * S * p.tq * D;
+    float M = -1e30f;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, ml[((bh * S + s) * p.tq + qi) * 2]);
+    float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const int64_t gq = (bh * S + s) * p.tq + qi;
+        const float w = exp2_fast(ml[gq * 2] - M);
+        L += w * ml[gq * 2 + 1];
+        const f32x4 v0 = *(const f32x4*)(part + gq * D + c8), v1 = *(const f32x4*)(part + gq * D + c8 + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] += w * v0[r]; acc[4 + r] += w * v1[r]; }
+    }
+    const float inv = 1.0f / L;
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    tx8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = from_f32<T>(acc[r] * inv);
+    *(tx8*)((T*)p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)h * D + c8) = o;
+}
+
 template <typename T>
 int launch_att_dma(const i2i_attention_params& p, hipStream_t s) {
-    const unsigned g2 = att_grid((p.tq + 127) / 128, p.heads, p.batch);
+    const int S = p.ksplit > 1 ? p.ksplit : 1;
+    const unsigned g2 = att_grid((p.tq + 127) / 128, p.heads * S, p.batch);
     const size_t smem = (size_t)3 * 2 * 64 * 128;
     const char* e = getenv("I2I_ATT_QF");                  // test / A-B hook: force the 128-query (2) or the 64-query (1) workgroup
     const int force = e ? atoi(e) : 0;
+    if (S > 1) {
+        if (force == 2 || (force != 1 && g2 >= 384)) hipLaunchKernelGGL((attention_dma_kernel<T, 2, true>), dim3(g2), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((attention_dma_kernel<T, 1, true>), dim3(att_grid((p.tq + 63) / 64, p.heads * S, p.batch)), dim3(256), smem, s, p);
+        const int rc = i2i::check_launch("attention_dma(split)");
+        if (rc != I2I_OK) return rc;
+        const int64_t nthr = (int64_t)p.batch * p.heads * p.tq * 8;
+        hipLaunchKernelGGL((attention_combine64_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
+        return i2i::check_launch("attention_combine64");
+    }
     if (force == 2 || (force != 1 && g2 >= 384)) hipLaunchKernelGGL((attention_dma_kernel<T, 2>), dim3(g2), dim3(256), smem, s, p);
     else hipLaunchKernelGGL((attention_dma_kernel<T, 1>), dim3(att_grid((p.tq + 63) / 64, p.heads, p.batch)), dim3(256), smem, s, p);
     return i2i::check_launch("attention_dma");
@@ -799,8 +872,9 @@ extern "C" int i2i_attention(const i2i_attention_params* p, int dtype, void* str
     // register-staged kernel
     const bool dma_ok = (p->ldo % 4 == 0) && (p->o_bs % 4 == 0) && (((uintptr_t)p->o & 7) == 0) && (((uintptr_t)p->k | (uintptr_t)p->vt) & 15) == 0 &&
                         (p->ldk % 8 == 0) && (p->k_bs % 8 == 0) && (p->vt_bs % 8 == 0);
-    if (p->ksplit > 1 && (p->d != 512 || dtype == I2I_F32 || !p->ws || (((uintptr_t)p->ws) & 15) || p->ldo % 8 || p->o_bs % 8 || (((uintptr_t)p->o) & 15)))
-        return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: ksplit is implemented by the d = 512 16-bit kernel and needs a 16-byte aligned workspace and output rows");
+    if (p->ksplit > 1 && (dtype == I2I_F32 || !p->ws || (((uintptr_t)p->ws) & 15) || p->ldo % 8 || p->o_bs % 8 || (((uintptr_t)p->o) & 15) ||
+                          (p->d == 64 && (!dma_ok || p->causal))))
+        return i2i::fail(I2I_ERR_UNSUPPORTED, "attention: ksplit is implemented by the 16-bit LDS-DMA kernels (no causal mask) and needs a 16-byte aligned workspace and output rows");
     if (p->d == 512) {
         if (!dma_ok || p->causal || p->ldq % 8 || (((uintptr_t)p->q) & 15) || p->q_bs % 8 || p->tk < 8 ||
             (int64_t)p->tk * p->ldk * 2 >= (int64_t(1) << 32) || (int64_t)p->d * p->heads * p->ldvt * 2 >= (int64_t(1) << 32))

@@ -135,6 +135,8 @@ class ForwardPlan:
         self.small_tile_k = int(os.environ.get("I2I_SMALL_TILE_K", "640"))
         self.small_tile_min_tiles = int(os.environ.get("I2I_SMALL_TILE_MIN_TILES", "128"))     # (the emulator tests lower it to reach the route)
         self.att_ksplit = os.environ.get("I2I_ATT_KSPLIT", "1") != "0"         # key-split VAE mid-block attention at small batch (A/B hook)
+        self.att_ksplit64 = int(os.environ.get("I2I_ATT_KSPLIT64", "4"))      # key splits of the d = 64 flash kernel on small grids (A/B hook)
+        self.att_ksplit64_min_tk = int(os.environ.get("I2I_ATT_KSPLIT64_MIN_TK", "2048"))     # (the emulator tests lower it to reach the route)
         self.att_q_log2 = os.environ.get("I2I_ATT_Q_LOG2", "1") != "0"         # scale * log2(e) folded into to_q for the flash kernel (A/B hook)
         self.vt_one_launch = os.environ.get("I2I_VT_ONE_LAUNCH", "1") != "0"   # self-attention V^T of all images in one wide-GEMM launch (A/B hook)
         # round 6: LayerNorm folded into the GEMM behind it (norm1 -> to_q | to_k | to_v^T in ONE launch, norm2 -> to_q, norm3 -> GEGLU on the
@@ -765,9 +767,18 @@ class ForwardPlan:
             self.flops += 2 * vb * tk * C * kv_cin
         o = self.pool.get(B * T * C, self.dtype)
         if self.flash and d == 64:
+            # few workgroups x many SERIAL key tiles (batch 1, T = 4096: 320 workgroups of 64 tiles at ~1 us each): keys divided among
+            # `ks` workgroups per query tile + the merge launch (csrc/attention.hip SPLIT; I2I_ATT_KSPLIT64 = splits, 0 = off)
+            ks, ws = 0, None
+            if (self.att_ksplit64 > 1 and self.dtype != torch.float32 and tk >= self.att_ksplit64_min_tk and B * heads * -(-T // 64) <= 512
+                    and C % 8 == 0 and (T * C) % 8 == 0):
+                ks = self.att_ksplit64
+                ws = self.pool.get(B * heads * ks * T * (d + 2), torch.float32)
             self._add(O.attention(q, k, vt, o, batch=B, heads=heads, d=d, tq=T, tk=tk, ldq=ldq, ldk=ldk, ldvt=ldvt, ldo=C,
-                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(vt_stride if vb > 1 else 0), o_bs=T * C, scale=scale), p + ".sdpa",
+                                  q_bs=q_bs, k_bs=k_bs, vt_bs=(vt_stride if vb > 1 else 0), o_bs=T * C, scale=scale, ksplit=ks, ws=ws), p + ".sdpa",
                       4 * B * heads * T * tk * d, kernel="attention_dma_kernel" if self.dtype != torch.float32 else "attention_kernel")
+            if ws is not None:
+                self.pool.put(ws)
         else:
             ldp = ldvt
             s = self.pool.get(B * heads * T * tk, torch.float32)

@@ -190,9 +190,10 @@ typedef struct {
     int32_t batch, heads, d, tq, tk, ldq, ldk, ldvt, ldo;
     int64_t q_bs, k_bs, vt_bs, o_bs; float scale;
     int32_t causal;            /* 1: query i attends to keys <= i (CLIP text tower); needs tq == tk */
-    int32_t ksplit;            /* > 1 (d = 512 kernel only): the keys are divided among ksplit workgroups per query tile and a
-                                  second launch merges the partial results -- for launches with too few query tiles to fill the
-                                  chip (batch 1: 32 tiles of 128 queries on 256 CUs).  Needs `ws`; 0 / 1 = off */
+    int32_t ksplit;            /* > 1 (the 16-bit LDS-DMA kernels, d = 512 and d = 64, no causal mask): the keys are divided among ksplit
+                                  workgroups per query tile and a second launch merges the partial results -- for launches with too few
+                                  query tiles to fill the chip (batch 1: 32 tiles of 128 queries on 256 CUs; the d = 64 self-attention
+                                  over 4096 tokens: 64 serial key tiles per workgroup).  Needs `ws`; 0 / 1 = off */
     void* ws;                  /* fp32 workspace for ksplit: batch*heads*ksplit*tq*(d + 2) floats, 16-byte aligned */
 } i2i_attention_params;
 

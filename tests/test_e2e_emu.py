@@ -49,11 +49,14 @@ def test_pix2pix_stochastic_twinconv_bf16(emu_lib, monkeypatch):
     assert err2 < 0.25, err2
     # the batch-1 route of the UNet's projections (64 x 32 tiles of the LDS-DMA igemm, no K slices), reached the same way
     monkeypatch.setenv("I2I_SMALL_TILE_MIN_TILES", "1")
+    monkeypatch.setenv("I2I_ATT_KSPLIT64_MIN_TK", "64")       # ... and the key-split self-attention (2 splits of the 64-key tiles + the merge launch)
+    monkeypatch.setenv("I2I_ATT_KSPLIT64", "2")
     model3 = Pix2Pix_Turbo(weights=as_product_weights(mw), device="cpu", dtype=torch.bfloat16, lib=emu_lib)
     out3 = model3(x, caption_enc=cap, eps=eps, deterministic=False, r=0.4, noise_map=nm)
     plan3 = list(model3._plans.values())[0]
     small = [p for (_o, _d, p, _l) in plan3.prog.ops if getattr(p, "tile", 0) == 26]
     assert len(small) >= 10 and all(p.splitk <= 1 for p in small), len(small)
+    assert any(getattr(p, "ksplit", 0) == 2 and p.d == 64 for (_o, _d, p, _l) in plan3.prog.ops if hasattr(p, "tq")), "no key-split attention in the plan"
     err3 = (out3.float() - ref).abs().max().item()
     assert err3 < 0.25, err3
     _check_plan_file_round_trip(emu_lib, model, x, cap, eps, nm, out)

@@ -260,6 +260,11 @@ def test_attention_dma_ring_and_tails(emu_lib, dtype, qf, monkeypatch):
     oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=2, tq=130, tk=264)
     oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, tq=33, tk=64)
     oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, tq=128, tk=325, spike=True)
+    # keys split over workgroups + the merge launch (the T = 4096 self-attention of a batch-1 forward): 5 key tiles over 2 splits (3 + 2),
+    # 6 tiles over 4 (2 + 2 + 2 + one EMPTY split), a partially valid last V^T chunk in the last split, the late spike
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=2, tq=130, tk=264, ksplit=2)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=2, heads=1, tq=33, tk=325, ksplit=4, spike=True)
+    oc.check_attention(emu_lib, "cpu", dtype, batch=1, heads=1, tq=70, tk=64, ksplit=3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

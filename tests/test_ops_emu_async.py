@@ -54,6 +54,7 @@ def test_dma_igemm_waits(async_lib, wgs, monkeypatch):
 
 def test_attention_waits(async_lib):
     oc.check_attention(async_lib, "cpu", torch.bfloat16, batch=1, heads=2, tq=130, tk=325, spike=True)        # d=64 ring of 3, 6 key tiles
+    oc.check_attention(async_lib, "cpu", torch.bfloat16, batch=1, heads=2, tq=130, tk=325, spike=True, ksplit=2)   # ring phases of a split that starts at tile 3
     oc.check_attention(async_lib, "cpu", torch.float16, batch=1, heads=1, d=512, tq=70, tk=77, spike=True)    # wide head, double buffer
 
 

@@ -237,6 +237,11 @@ def test_attention_dma_large(gpu_lib, dtype):
     oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=5, tq=4096, tk=4096)     # UNet level 0 self-attention
     oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=2, tq=130, tk=325, spike=True)
     oc.check_attention(gpu_lib, "cuda", dtype, batch=3, heads=20, tq=64, tk=77)
+    # key-split + merge launch (batch-1 self-attention): 64 key tiles over 4 / 2 splits, ragged, one empty split
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=5, tq=4096, tk=4096, ksplit=4)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=10, tq=1024, tk=1024, ksplit=2, seed=1)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=1, heads=2, tq=130, tk=325, spike=True, ksplit=4)
+    oc.check_attention(gpu_lib, "cuda", dtype, batch=2, heads=1, tq=70, tk=128, ksplit=3)
 
 
 @pytest.mark.gpu
